@@ -12,7 +12,26 @@ CXXFLAGS ?= -O3 -std=c++17 -Wall -Wextra -fPIC
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wextra -Wno-unused-parameter
 CSRC     := ntsm_amd/csrc
 
-all: oracle_all build/ntsm_synth
+HOST     := $(CSRC)/host
+HOSTSRC  := $(HOST)/seq_reader.cpp $(HOST)/site_set.cpp $(HOST)/report.cpp
+HOSTHDR  := $(wildcard $(HOST)/*.hpp) include/ntsm_host.h include/ntsm_hip.h
+
+all: oracle_all build/ntsm_synth build/gather_bench ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount
+
+# host-only pieces (reader, site loader, report formatting): no HIP dependency
+ntsm_amd/libntsm_host.so: $(HOSTSRC) $(HOST)/host_capi.cpp $(HOSTHDR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC) $(HOST)/host_capi.cpp -lz
+
+build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp $(HOSTHDR) ntsm_amd/libntsm_hip.so
+	@mkdir -p build
+	$(CXX) $(CXXFLAGS) -o $@ $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp \
+	    -Lntsm_amd -lntsm_hip -lz -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
+
+ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_device.h include/ntsm_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ntsm_hip.hip -L/opt/rocm/lib -lrccl
+
+ntsm_amd/libntsm_synth.so: $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp -lz
 
 oracle_all:
 	$(MAKE) -C oracle all
@@ -20,6 +39,10 @@ oracle_all:
 build/ntsm_synth: tools/ntsm_synth.cpp $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
 	@mkdir -p build
 	$(CXX) $(CXXFLAGS) tools/ntsm_synth.cpp $(CSRC)/synth_host.cpp -o $@ -lz
+
+build/gather_bench: tools/gather_bench.hip
+	@mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) tools/gather_bench.hip -o $@
 
 clean:
 	rm -rf build ntsm_amd/*.so

@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- bases/s through the ntsmCount hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the count path over the whole resident workload (BASELINE.json configs[1]:
+1e9 synthetic 150 bp reads against the 96287-site hs_n10_like set, k = 19), inputs already in HBM.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own 1e9 reads
+(weak scaling, configs[3]); each step ends with one RCCL SUM of the per-k-mer count vector + totals.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the count kernel: algorithmic bytes =
+(L + 8) / L per base over the HIP-event launch time; `cpu_baseline` is the CPU
+restatement of the reference (oracle/ntsm_oracle) timed on a bounded sample of the same reads.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+SITES_SEED, N_SITES, READ_SEED, READ_LEN, K = 20241218, 96287, 7, 150, 19
+
+
+def cpu_baseline(synth, sites_path, n_reads):
+    """Time the CPU restatement (oracle/ntsm_oracle, 1 thread, FASTQ in, site-table build excluded)."""
+    exe = os.path.join(ROOT, "oracle", "ntsm_oracle")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        fq = os.path.join(d, "sample.fq")
+        synth.write_fastq(fq, 0, n_reads)
+        p = subprocess.run([exe, "-s", sites_path, "--time-scan", fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    for line in p.stderr.decode().split("\n"):
+        if line.startswith("SCAN_SECONDS"):
+            f = line.split()
+            secs, bases = float(f[1]), int(f[3])
+            return {"value": bases / secs, "unit": "bases/s", "cores": 1, "kind": "port",
+                    "sample": "first %d reads of the same synthetic stream as FASTQ (%d bases, %.1f s scan, table build excluded)"
+                              % (n_reads, bases, secs)}
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=float, default=float(os.environ.get("NTSM_BENCH_READS", 1e9)),
+                    help="reads per GPU (default 1e9 = BASELINE.json configs[1])")
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--filter-log2", type=int, default=0)
+    ap.add_argument("--grid", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ntsm_amd
+    from ntsm_amd.dist import merge_counts, shard_range
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the count path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_reads = int(args.reads)
+    tmp = tempfile.mkdtemp(prefix="ntsm_bench_")
+    sites_path = os.path.join(tmp, "hs_n10_like.fa")
+    synth = ntsm_amd.SynthShort(SITES_SEED, N_SITES, k=K, read_seed=READ_SEED, read_len=READ_LEN,
+                                sites_path=sites_path)
+    sites = ntsm_amd.Sites(sites_path, k=K)
+    ctx = ntsm_amd.Context(sites.keys, k=K, device=local)
+    if args.filter_log2 or args.grid:
+        ctx.set_tuning(args.filter_log2, args.grid)
+
+    # workload resident in HBM: this rank's reads [rank*n, (rank+1)*n) of the global synthetic stream
+    d_win = torch.from_numpy(synth.windows).to(dev)
+    while True:
+        try:
+            d_bases = torch.empty(n_reads * synth.stride, dtype=torch.uint8, device=dev)
+            break
+        except RuntimeError:                       # smaller GPU: halve until it fits, and say so in config
+            n_reads //= 2
+            if n_reads < 1000:
+                raise
+    synth.device_fill(d_win.data_ptr(), rank * n_reads, n_reads, d_bases.data_ptr())
+    torch.cuda.synchronize()
+    n_bytes = d_bases.numel()
+    bases_per_step = n_reads * READ_LEN
+
+    def run_step():
+        ctx.count_resident(d_bases.data_ptr(), n_bytes, 0, n_reads)
+        if world > 1:
+            merge_counts(ctx)
+
+    for _ in range(args.warmup):
+        run_step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ctx.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_launch, kernel_ms = ctx.get_timing()
+    totals = ctx.sync()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        value = world * bases_per_step * args.steps / elapsed
+        launch_s = kernel_ms / 1e3 / max(n_launch, 1)
+        bytes_per_base = (READ_LEN + 8) / READ_LEN
+        achieved = bases_per_step * bytes_per_base / launch_s / 1e9
+        out = {
+            "metric": "bases/s through ntsmCount count path, 150 bp reads vs hs_n10_like (96287 sites)",
+            "value": value, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "reads_per_s": world * n_reads * args.steps / elapsed,
+            "config": {"workload": "configs[1]: %.3g synthetic 150 bp reads per GPU resident in HBM, hs_n10_like sites "
+                                   "(96287 sites, %d distinct 19-mers), k=19" % (n_reads, len(sites.keys)),
+                       "reads_per_gpu": n_reads, "read_len": READ_LEN, "k": K, "n_sites": N_SITES,
+                       "parallelism": "reads sharded over %d GPU(s); one RCCL SUM of per-k-mer counts per step" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ntsm_count_kernel", "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
+                         "algorithmic_bytes_per_base": bytes_per_base,
+                         "kmer_probe_rate_per_s": totals.total_kmers / max(args.steps + args.warmup, 1) / launch_s},
+            "check": {"total_kmers_per_step": totals.total_kmers // (args.steps + args.warmup) if world == 1 else None,
+                      "total_hits_per_step": totals.total_hits // (args.steps + args.warmup) if world == 1 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(synth, sites_path, args.cpu_sample_reads)
+            if cb:
+                out["cpu_baseline"] = cb
+                out["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+/*
+ * include/ntsm_hip.h -- C ABI of the MI355X (gfx950) k-mer counting hot path of ntsmCount.
+ *
+ * The reference (JustinChu/ntsm v1.2.1) has no plugin/FFI layer; its seam is the FingerPrint
+ * class that src/ntSeqMatchCount.cpp:177-181 drives.  This library replaces what happens
+ * INSIDE that class between site loading and printing:
+ *
+ *   reference (CPU)                                            this ABI (HIP)
+ *   ---------------------------------------------------------  --------------------------------
+ *   tsl::robin_map<uint64_t,size_t> m_counts filled with       ntsm_create(keys, n_kmers, ...)
+ *     m_counts[hv] = 0        (src/FingerPrint.hpp:528,:550)
+ *   m_maxCounts = size*covThresh/2   (src/FingerPrint.hpp:41)  ntsm_create(..., max_hits)
+ *   per read: insertCount(seq.s, seq.l)  -> KseqHashIterator   ntsm_submit / ntsm_submit_staged /
+ *     + m_counts.find + atomic +=  (src/FingerPrint.hpp:89-103,  ntsm_count_resident   (batched)
+ *     vendor/KseqHashIterator.hpp:87-139)
+ *   processSingleRead's -m check (src/FingerPrint.hpp:473-488)  ntsm_sync -> ntsm_totals.early_stop
+ *   m_totalKmers / m_totalCounts / m_totalBases                ntsm_sync -> ntsm_totals
+ *   m_counts.at(hv) at print time (src/FingerPrint.hpp:282)    ntsm_counts (dense, key order)
+ *   (none: single process)                                     ntsm_counts_device + RCCL SUM
+ *
+ * Flat read-stream layout consumed by submit/count: the reads of a batch are concatenated, each
+ * read followed by exactly ONE terminator byte 'N' (an invalid base resets the k-mer window
+ * exactly like vendor/KseqHashIterator.hpp:106, so no k-mer spans two reads).  read_end[i] is
+ * the offset of read i's terminator; read i spans [i ? read_end[i-1]+1 : 0, read_end[i]);
+ * n_bytes == read_end[n_reads-1] + 1.  Bases are the raw bytes of seq.s: the kernel applies
+ * the reference's byte->code table itself (vendor/KseqHashIterator.hpp:114-127).
+ *
+ * Conventions: every function returns NTSM_OK (0) or a negative NTSM_ERR_* code
+ * (ntsm_strerror); no C++ types or exceptions cross the boundary; the caller owns every
+ * buffer it passes; a context owns its device memory and streams and must be driven by one
+ * host thread at a time.  There is NO CPU fallback: without a usable HIP device ntsm_create
+ * fails with NTSM_ERR_NO_DEVICE.
+ */
+#ifndef NTSM_HIP_H
+#define NTSM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ntsm_ctx ntsm_ctx;
+
+/* Cumulative totals of a context (the reference's m_totalKmers, m_totalCounts, m_totalBases). */
+typedef struct {
+	uint64_t total_kmers;      /* valid k-mer windows seen, hits or not  (src/FingerPrint.hpp:98-99) */
+	uint64_t total_hits;       /* windows found in the site set          (src/FingerPrint.hpp:96-97) */
+	uint64_t total_bases;      /* sum of read lengths, 'N' included      (src/FingerPrint.hpp:101-102) */
+	uint64_t reads_consumed;   /* reads that contributed (all submitted reads unless early_stop) */
+	int32_t  early_stop;       /* 1 once total_hits > max_hits after a whole read (src/FingerPrint.hpp:476-487) */
+	int32_t  reserved;
+} ntsm_totals;
+
+enum {
+	NTSM_OK = 0,
+	NTSM_ERR_ARG = -1,         /* bad argument (NULL, k out of range, misaligned device pointer, bad layout) */
+	NTSM_ERR_NO_DEVICE = -2,   /* no usable HIP device / device index out of range */
+	NTSM_ERR_HIP = -3,         /* a HIP runtime call failed (ntsm_last_hip_error) */
+	NTSM_ERR_DUP_KEY = -4,     /* duplicate key in the k-mer set */
+	NTSM_ERR_NOMEM = -5,
+	NTSM_ERR_STATE = -6,       /* call not valid in the current state (e.g. staged slot not acquired) */
+	NTSM_ERR_RCCL = -7
+};
+
+enum {
+	NTSM_KEYS_CANONICAL = 0,   /* keys are canonical 2-bit codes min(fw, rc) (KseqHashIterator.hpp:102-104) */
+	NTSM_KEYS_HASH64 = 1       /* keys are hash64(canonical, mask): exactly m_counts' keys (KseqHashIterator.hpp:129-139) */
+};
+
+/* Build a context on HIP device `device`.
+ *   k        : k-mer size, 1..32 (src/ntSeqMatchCount.cpp:147-150; k = 32 mirrors the reference's
+ *              degenerate mask = 0)
+ *   keys     : n_kmers distinct keys; the dense index of a key is its position in this array
+ *   key_kind : NTSM_KEYS_CANONICAL or NTSM_KEYS_HASH64 (inverted on the host; hash64 is a bijection)
+ *   max_hits : the reference's m_maxCounts; 0 disables the -m early stop */
+int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_t n_kmers,
+		int key_kind, uint64_t max_hits);
+void ntsm_destroy(ntsm_ctx *ctx);
+
+/* Count one batch of reads held in HOST memory (copied into pinned staging, then asynchronous
+ * H2D + kernel on one of two internal streams).  The caller's buffers may be reused on return. */
+int ntsm_submit(ntsm_ctx *ctx, const uint8_t *bases, uint64_t n_bytes, const uint64_t *read_end,
+		uint32_t n_reads);
+
+/* Zero-copy variant: parse straight into pinned staging.  acquire blocks until the slot's previous
+ * batch has left the host buffer; fill at most *cap_bytes bases / *cap_reads offsets, then submit. */
+int ntsm_staging_acquire(ntsm_ctx *ctx, uint8_t **bases, uint64_t *cap_bytes, uint64_t **read_end,
+		uint64_t *cap_reads);
+int ntsm_submit_staged(ntsm_ctx *ctx, uint64_t n_bytes, uint32_t n_reads);
+/* Resize the two staging slots (default 64 MiB of bases, 1 Mi reads each). */
+int ntsm_set_batch_capacity(ntsm_ctx *ctx, uint64_t cap_bytes, uint64_t cap_reads);
+
+/* Count a batch already RESIDENT in device memory (d_bases 16-byte aligned).  d_read_end may be
+ * NULL when the context has no early stop armed (max_hits == 0).  sign = +1 counts, -1 removes
+ * the batch's contribution again (exact: integer adds).  Asynchronous on the context's stream. */
+int ntsm_count_resident(ntsm_ctx *ctx, const void *d_bases, uint64_t n_bytes, const void *d_read_end,
+		uint64_t n_reads, int sign);
+
+/* Drain all streams; fill cumulative totals. */
+int ntsm_sync(ntsm_ctx *ctx, ntsm_totals *totals);
+/* Per-k-mer counts (dense, in key order), 64-bit like m_counts' mapped size_t.  Implies a sync. */
+int ntsm_counts(ntsm_ctx *ctx, uint64_t *out);
+/* Device pointer to the dense uint64 count vector followed by 4 uint64 totals
+ * {kmers, hits, bases, reads}: n_kmers + 4 words, refreshed by this call (implies a sync), for a
+ * caller-run RCCL SUM (torch.distributed all_reduce); ntsm_import_reduced loads the reduced
+ * vector back so that ntsm_counts/ntsm_sync report job-wide values. */
+int ntsm_counts_device(ntsm_ctx *ctx, void **d_vec, uint64_t *n_words);
+int ntsm_import_reduced(ntsm_ctx *ctx);
+/* Single-process multi-GPU merge: RCCL SUM over the n contexts' count vectors + totals (xGMI). */
+int ntsm_allreduce(ntsm_ctx *const *ctxs, int n);
+/* Forget all counts and totals (table stays). */
+int ntsm_reset(ntsm_ctx *ctx);
+
+/* Kernel timing for bench.py: when on, every count launch is bracketed by hipEvents on the stream
+ * it runs on; get returns the number of launches and the sum of their durations since `on`. */
+int ntsm_set_timing(ntsm_ctx *ctx, int on);
+int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
+/* Tuning knobs (0 = automatic): log2 of filter bits, grid blocks.  For profiling experiments. */
+int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
+/* The HIP stream (hipStream_t) ntsm_count_resident launches on. */
+void *ntsm_stream(ntsm_ctx *ctx);
+
+/* Host helpers: the reference's hash64 and its inverse on 2k bits (KseqHashIterator.hpp:129-139). */
+uint64_t ntsm_hash64(uint64_t key, int k);
+uint64_t ntsm_hash64_inv(uint64_t hv, int k);
+
+const char *ntsm_strerror(int code);
+int ntsm_last_hip_error(void);
+const char *ntsm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTSM_HIP_H */

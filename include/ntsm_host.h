@@ -1,0 +1,51 @@
+/*
+ * include/ntsm_host.h -- C ABI over the host-side pieces of ntsmCount (site loading, read
+ * flattening, report formatting) so that tests and bench.py can drive them without the CLI.
+ * None of these functions touches a GPU.  Reference behaviour each one reproduces:
+ *   ntsm_sites_*          FingerPrint::initCountsHash            src/FingerPrint.hpp:490-564
+ *   ntsm_host_flatten     kseq_read loop of computeCounts        src/FingerPrint.hpp:64-69, vendor/kseq.h:177-219
+ *   ntsm_host_format_*    printOptionalHeader/printCountsMax/    src/FingerPrint.hpp:261-349
+ *                         printInfoSummary
+ *   ntsm_host_max_hits    m_maxCounts                            src/FingerPrint.hpp:41-43
+ */
+#ifndef NTSM_HOST_H
+#define NTSM_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ntsm_sites ntsm_sites;
+
+/* Load a sites file.  Returns 0, or -1 if it cannot be opened.  Collision warnings go to stderr. */
+int ntsm_sites_load(const char *path, unsigned k, int allow_dupes, ntsm_sites **out);
+void ntsm_sites_free(ntsm_sites *s);
+uint64_t ntsm_sites_n_keys(const ntsm_sites *s);          /* m_counts.size() */
+const uint64_t *ntsm_sites_keys(const ntsm_sites *s);     /* canonical codes, first-seen order */
+uint64_t ntsm_sites_n_sites(const ntsm_sites *s);         /* m_alleleIDs.size() */
+uint64_t ntsm_sites_n_erased(const ntsm_sites *s);        /* duplicates removed (no -d) */
+
+/* m_maxCounts for a k-mer set size and the -m value (0 = disabled / never) */
+uint64_t ntsm_host_max_hits(uint64_t n_distinct, double cov_thresh);
+
+/* Parse one FASTA/FASTQ(.gz) file into the flat stream layout of include/ntsm_hip.h.
+ * Buffers are malloc'ed; release with ntsm_host_free.  *last_rc = the reader's terminating code
+ * (-1 EOF, -2 truncated quality, -3 stream error).  Returns 0, or -1 if the file cannot be opened. */
+int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint64_t **read_end,
+		uint64_t *n_reads, int *last_rc);
+void ntsm_host_free(void *p);
+
+/* counts.txt bytes for per-k-mer counts in key order.  Returns 0, or 1 if the reference would
+ * abort while printing (then *out holds the rows written before the abort). */
+int ntsm_host_format_counts(const ntsm_sites *s, const uint64_t *counts, uint64_t total_kmers,
+		char **out, size_t *len);
+/* six-line summary; *covered receives "Sites Covered by at least one k-mer". */
+int ntsm_host_format_summary(const ntsm_sites *s, const uint64_t *counts, uint64_t total_bases,
+		uint64_t total_kmers, uint64_t total_hits, char **out, size_t *len, uint64_t *covered);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,297 @@
+"""ctypes bindings of include/ntsm_hip.h, include/ntsm_host.h and include/ntsm_synth.h."""
+import ctypes as C
+import os
+
+import numpy as np
+
+# torch bundles its own libamdhip64/librccl (same SONAMEs as /opt/rocm's).  Loading torch FIRST makes
+# the dynamic linker hand that one runtime to libntsm_hip.so too; the other order would put two HIP
+# runtimes in one process (device pointers and streams would not be interchangeable).
+import torch  # noqa: F401,E402
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class NtsmError(RuntimeError):
+    pass
+
+
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `make` at the repo root (the HIP path has no CPU fallback)" % path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+hip_lib = _load("libntsm_hip.so")
+host_lib = _load("libntsm_host.so")
+synth_lib = _load("libntsm_synth.so")
+
+u8p, u64p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+
+
+class Totals(C.Structure):
+    _fields_ = [("total_kmers", C.c_uint64), ("total_hits", C.c_uint64), ("total_bases", C.c_uint64),
+                ("reads_consumed", C.c_uint64), ("early_stop", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SynthShortParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("n_sites", C.c_uint32), ("embed_thr", C.c_uint32),
+                ("sub_thr", C.c_uint32), ("n_thr", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class SynthLongParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_sites", C.c_uint32), ("spacing", C.c_uint32),
+                ("sub_thr", C.c_uint32), ("n_thr", C.c_uint32)]
+
+
+def _sig(lib, name, res, args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = args
+    return f
+
+
+H = hip_lib
+_sig(H, "ntsm_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, u64p, C.c_uint32, C.c_int, C.c_uint64])
+_sig(H, "ntsm_destroy", None, [C.c_void_p])
+_sig(H, "ntsm_submit", C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, C.c_uint32])
+_sig(H, "ntsm_staging_acquire", C.c_int, [C.c_void_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p])
+_sig(H, "ntsm_submit_staged", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32])
+_sig(H, "ntsm_set_batch_capacity", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64])
+_sig(H, "ntsm_count_resident", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int])
+_sig(H, "ntsm_sync", C.c_int, [C.c_void_p, C.POINTER(Totals)])
+_sig(H, "ntsm_counts", C.c_int, [C.c_void_p, u64p])
+_sig(H, "ntsm_counts_device", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), u64p])
+_sig(H, "ntsm_import_reduced", C.c_int, [C.c_void_p])
+_sig(H, "ntsm_allreduce", C.c_int, [C.POINTER(C.c_void_p), C.c_int])
+_sig(H, "ntsm_reset", C.c_int, [C.c_void_p])
+_sig(H, "ntsm_set_timing", C.c_int, [C.c_void_p, C.c_int])
+_sig(H, "ntsm_get_timing", C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_double)])
+_sig(H, "ntsm_set_tuning", C.c_int, [C.c_void_p, C.c_int, C.c_int])
+_sig(H, "ntsm_stream", C.c_void_p, [C.c_void_p])
+_sig(H, "ntsm_hash64", C.c_uint64, [C.c_uint64, C.c_int])
+_sig(H, "ntsm_hash64_inv", C.c_uint64, [C.c_uint64, C.c_int])
+_sig(H, "ntsm_strerror", C.c_char_p, [C.c_int])
+_sig(H, "ntsm_last_hip_error", C.c_int, [])
+_sig(H, "ntsm_version", C.c_char_p, [])
+
+HO = host_lib
+_sig(HO, "ntsm_sites_load", C.c_int, [C.c_char_p, C.c_uint, C.c_int, C.POINTER(C.c_void_p)])
+_sig(HO, "ntsm_sites_free", None, [C.c_void_p])
+_sig(HO, "ntsm_sites_n_keys", C.c_uint64, [C.c_void_p])
+_sig(HO, "ntsm_sites_keys", u64p, [C.c_void_p])
+_sig(HO, "ntsm_sites_n_sites", C.c_uint64, [C.c_void_p])
+_sig(HO, "ntsm_sites_n_erased", C.c_uint64, [C.c_void_p])
+_sig(HO, "ntsm_host_max_hits", C.c_uint64, [C.c_uint64, C.c_double])
+_sig(HO, "ntsm_host_flatten", C.c_int, [C.c_char_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, C.POINTER(C.c_int)])
+_sig(HO, "ntsm_host_free", None, [C.c_void_p])
+_sig(HO, "ntsm_host_format_counts", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)])
+_sig(HO, "ntsm_host_format_summary", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), u64p])
+
+SY = synth_lib
+_sig(SY, "ntsm_synth_sites", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint, u8p, C.c_char_p, u64p])
+_sig(SY, "ntsm_synth_short_params", None, [C.POINTER(SynthShortParams), C.c_uint64, C.c_uint32, C.c_uint32,
+                                           C.c_double, C.c_double, C.c_double])
+_sig(SY, "ntsm_synth_long_params", None, [C.POINTER(SynthLongParams), C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_double])
+_sig(SY, "ntsm_synth_long_qtable", None, [C.c_double, C.c_double, C.c_uint32, C.c_uint32, u32p])
+_sig(SY, "ntsm_synth_long_layout", C.c_uint64, [C.c_uint64, u32p, C.c_uint64, C.c_uint64, u64p])
+_sig(SY, "ntsm_synth_short_fill_host", None, [C.POINTER(SynthShortParams), u8p, C.c_uint64, C.c_uint64, u8p])
+_sig(SY, "ntsm_synth_long_fill_host", None, [C.POINTER(SynthLongParams), u8p, u32p, C.c_uint64, C.c_uint64, u64p, u8p])
+_sig(SY, "ntsm_synth_short_fill_device", C.c_int, [C.POINTER(SynthShortParams), C.c_void_p, C.c_uint64, C.c_uint64,
+                                                   C.c_void_p, C.c_void_p])
+_sig(SY, "ntsm_synth_long_fill_device", C.c_int, [C.POINTER(SynthLongParams), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                                  C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p])
+_sig(SY, "ntsm_synth_short_write_fastq", C.c_int, [C.POINTER(SynthShortParams), u8p, C.c_uint64, C.c_uint64, C.c_char_p])
+_sig(SY, "ntsm_synth_long_write_fastq", C.c_int, [C.POINTER(SynthLongParams), u8p, u32p, C.c_uint64, C.c_uint64, C.c_char_p])
+
+KEYS_CANONICAL, KEYS_HASH64 = 0, 1
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise NtsmError("%s: %s (code %d, hipError %d)" % (what, H.ntsm_strerror(rc).decode(), rc, H.ntsm_last_hip_error()))
+
+
+def _p(arr, typ):
+    return arr.ctypes.data_as(typ)
+
+
+def hash64(key, k):
+    return int(H.ntsm_hash64(int(key), int(k)))
+
+
+def hash64_inv(hv, k):
+    return int(H.ntsm_hash64_inv(int(hv), int(k)))
+
+
+def max_hits_for(n_distinct, cov_thresh):
+    return int(HO.ntsm_host_max_hits(int(n_distinct), float(cov_thresh)))
+
+
+class Sites:
+    """Host-side site set (FingerPrint::initCountsHash, src/FingerPrint.hpp:490-564)."""
+
+    def __init__(self, path, k=19, allow_dupes=False):
+        h = C.c_void_p()
+        if HO.ntsm_sites_load(os.fsencode(path), k, int(allow_dupes), C.byref(h)) != 0:
+            raise NtsmError("file %s cannot be opened" % path)
+        self._h, self.k = h, k
+        n = HO.ntsm_sites_n_keys(h)
+        self.keys = np.ctypeslib.as_array(HO.ntsm_sites_keys(h), shape=(n,)).copy() if n else np.zeros(0, np.uint64)
+        self.n_sites = int(HO.ntsm_sites_n_sites(h))
+        self.n_erased = int(HO.ntsm_sites_n_erased(h))
+
+    def format_counts(self, counts, total_kmers):
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        out, ln = C.c_void_p(), C.c_size_t()
+        rc = HO.ntsm_host_format_counts(self._h, _p(counts, u64p), int(total_kmers), C.byref(out), C.byref(ln))
+        data = C.string_at(out, ln.value)
+        HO.ntsm_host_free(out)
+        return rc, data
+
+    def format_summary(self, counts, total_bases, total_kmers, total_hits):
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        out, ln, cov = C.c_void_p(), C.c_size_t(), C.c_uint64()
+        HO.ntsm_host_format_summary(self._h, _p(counts, u64p), int(total_bases), int(total_kmers), int(total_hits),
+                                    C.byref(out), C.byref(ln), C.byref(cov))
+        data = C.string_at(out, ln.value)
+        HO.ntsm_host_free(out)
+        return data, int(cov.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            HO.ntsm_sites_free(self._h)
+            self._h = None
+
+
+def flatten_file(path):
+    """Parse a FASTA/FASTQ(.gz) file into (bases uint8[n_bytes], read_end uint64[n_reads], last_rc)."""
+    b, e = u8p(), u64p()
+    nb, nr, rc = C.c_uint64(), C.c_uint64(), C.c_int()
+    if HO.ntsm_host_flatten(os.fsencode(path), C.byref(b), C.byref(nb), C.byref(e), C.byref(nr), C.byref(rc)) != 0:
+        raise NtsmError("file %s cannot be opened" % path)
+    bases = np.ctypeslib.as_array(b, shape=(nb.value,)).copy() if nb.value else np.zeros(0, np.uint8)
+    ends = np.ctypeslib.as_array(e, shape=(nr.value,)).copy() if nr.value else np.zeros(0, np.uint64)
+    HO.ntsm_host_free(b)
+    HO.ntsm_host_free(e)
+    return bases, ends, rc.value
+
+
+def flatten_reads(reads):
+    """Flat-stream layout from a list of bytes objects."""
+    parts, ends, off = [], [], 0
+    for r in reads:
+        parts.append(bytes(r))
+        parts.append(b"N")
+        off += len(r)
+        ends.append(off)
+        off += 1
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy(), np.asarray(ends, dtype=np.uint64)
+
+
+class Context:
+    """One GPU context (include/ntsm_hip.h)."""
+
+    def __init__(self, keys, k=19, device=0, key_kind=KEYS_CANONICAL, max_hits=0):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        self._h = C.c_void_p()
+        self.n_kmers, self.k = len(keys), k
+        _chk(H.ntsm_create(C.byref(self._h), device, k, _p(keys, u64p), len(keys), key_kind, int(max_hits)), "ntsm_create")
+
+    def submit(self, bases, read_end):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_end = np.ascontiguousarray(read_end, dtype=np.uint64)
+        _chk(H.ntsm_submit(self._h, _p(bases, u8p), bases.size, _p(read_end, u64p), read_end.size), "ntsm_submit")
+
+    def set_batch_capacity(self, cap_bytes, cap_reads):
+        _chk(H.ntsm_set_batch_capacity(self._h, cap_bytes, cap_reads), "ntsm_set_batch_capacity")
+
+    def count_resident(self, d_bases_ptr, n_bytes, d_read_end_ptr, n_reads, sign=1):
+        _chk(H.ntsm_count_resident(self._h, C.c_void_p(d_bases_ptr), n_bytes,
+                                   C.c_void_p(d_read_end_ptr) if d_read_end_ptr else None, n_reads, sign), "ntsm_count_resident")
+
+    def sync(self):
+        t = Totals()
+        _chk(H.ntsm_sync(self._h, C.byref(t)), "ntsm_sync")
+        return t
+
+    def counts(self):
+        out = np.zeros(self.n_kmers, dtype=np.uint64)
+        _chk(H.ntsm_counts(self._h, _p(out, u64p)), "ntsm_counts")
+        return out
+
+    def counts_device(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(H.ntsm_counts_device(self._h, C.byref(p), C.byref(n)), "ntsm_counts_device")
+        return p.value, n.value
+
+    def import_reduced(self):
+        _chk(H.ntsm_import_reduced(self._h), "ntsm_import_reduced")
+
+    def reset(self):
+        _chk(H.ntsm_reset(self._h), "ntsm_reset")
+
+    def set_timing(self, on):
+        _chk(H.ntsm_set_timing(self._h, int(on)), "ntsm_set_timing")
+
+    def get_timing(self):
+        n, ms = C.c_uint64(), C.c_double()
+        _chk(H.ntsm_get_timing(self._h, C.byref(n), C.byref(ms)), "ntsm_get_timing")
+        return n.value, ms.value
+
+    def set_tuning(self, filter_log2_bits=0, grid_blocks=0):
+        _chk(H.ntsm_set_tuning(self._h, filter_log2_bits, grid_blocks), "ntsm_set_tuning")
+
+    @property
+    def stream(self):
+        return H.ntsm_stream(self._h)
+
+    def close(self):
+        if self._h:
+            H.ntsm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SynthShort:
+    """Seeded short-read workload (ntsm_amd/csrc/synth.h); sites + reads share one object."""
+
+    def __init__(self, sites_seed, n_sites, k=19, read_seed=7, read_len=150, p_embed=0.10, p_sub=0.01, p_n=5e-4,
+                 sites_path=None):
+        self.n_sites, self.k, self.read_len = n_sites, k, read_len
+        self.windows = np.zeros(n_sites * 2 * 32, dtype=np.uint8)
+        nk = C.c_uint64()
+        rc = SY.ntsm_synth_sites(sites_seed, n_sites, k, _p(self.windows, u8p),
+                                 os.fsencode(sites_path) if sites_path else None, C.byref(nk))
+        if rc:
+            raise NtsmError("ntsm_synth_sites failed: %d" % rc)
+        self.n_kmers = int(nk.value)
+        self.params = SynthShortParams()
+        SY.ntsm_synth_short_params(C.byref(self.params), read_seed, read_len, n_sites, p_embed, p_sub, p_n)
+        self.stride = read_len + 1
+
+    def host_bytes(self, r0, n_reads):
+        out = np.zeros(n_reads * self.stride, dtype=np.uint8)
+        SY.ntsm_synth_short_fill_host(C.byref(self.params), _p(self.windows, u8p), r0 * self.stride, out.size, _p(out, u8p))
+        return out
+
+    def read_end(self, n_reads):
+        return (np.arange(n_reads, dtype=np.uint64) * np.uint64(self.stride)) + np.uint64(self.read_len)
+
+    def device_fill(self, d_windows_ptr, r0, n_reads, d_out_ptr, stream=None):
+        rc = SY.ntsm_synth_short_fill_device(C.byref(self.params), C.c_void_p(d_windows_ptr), r0 * self.stride,
+                                             n_reads * self.stride, C.c_void_p(d_out_ptr), C.c_void_p(stream) if stream else None)
+        if rc:
+            raise NtsmError("device fill failed: %d" % rc)
+
+    def write_fastq(self, path, r0, n_reads):
+        rc = SY.ntsm_synth_short_write_fastq(C.byref(self.params), _p(self.windows, u8p), r0, n_reads, os.fsencode(path))
+        if rc:
+            raise NtsmError("write_fastq failed: %d" % rc)

@@ -1,0 +1,94 @@
+#include "../../../include/ntsm_host.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+
+#include "report.hpp"
+#include "seq_reader.hpp"
+#include "site_set.hpp"
+
+struct ntsm_sites {
+	ntsm::SiteSet set;
+};
+
+static char *dup_string(const std::string &s, size_t *len)
+{
+	char *p = (char *) malloc(s.size() + 1);
+	memcpy(p, s.data(), s.size());
+	p[s.size()] = 0;
+	if (len) *len = s.size();
+	return p;
+}
+
+extern "C" {
+
+int ntsm_sites_load(const char *path, unsigned k, int allow_dupes, ntsm_sites **out)
+{
+	if (!path || !out) return -1;
+	ntsm_sites *s = new ntsm_sites();
+	if (!s->set.load(path, k, allow_dupes != 0, std::cerr)) { delete s; return -1; }
+	*out = s;
+	return 0;
+}
+void ntsm_sites_free(ntsm_sites *s) { delete s; }
+uint64_t ntsm_sites_n_keys(const ntsm_sites *s) { return s->set.keys.size(); }
+const uint64_t *ntsm_sites_keys(const ntsm_sites *s) { return s->set.keys.data(); }
+uint64_t ntsm_sites_n_sites(const ntsm_sites *s) { return s->set.ids.size(); }
+uint64_t ntsm_sites_n_erased(const ntsm_sites *s) { return s->set.n_erased; }
+
+uint64_t ntsm_host_max_hits(uint64_t n_distinct, double cov)
+{
+	if (cov == 0) return 0;
+	const double x = ((double) n_distinct * cov) / 2;
+	if (!(x == x) || x >= 18446744073709551616.0) return 0;
+	if (x < 0) return UINT64_MAX;
+	return (uint64_t) x;
+}
+
+int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint64_t **read_end,
+		uint64_t *n_reads, int *last_rc)
+{
+	ntsm::SeqReader rd;
+	if (!rd.open(path)) return -1;
+	std::vector<uint8_t> b;
+	std::vector<uint64_t> e;
+	int64_t l;
+	while ((l = rd.next()) >= 0) {
+		b.insert(b.end(), rd.seq().begin(), rd.seq().begin() + l);
+		e.push_back(b.size());
+		b.push_back('N');
+	}
+	if (last_rc) *last_rc = (int) l;
+	*bases = (uint8_t *) malloc(b.size() + 16);
+	memcpy(*bases, b.data(), b.size());
+	*n_bytes = b.size();
+	*read_end = (uint64_t *) malloc((e.size() + 1) * sizeof(uint64_t));
+	memcpy(*read_end, e.data(), e.size() * sizeof(uint64_t));
+	*n_reads = e.size();
+	return 0;
+}
+
+void ntsm_host_free(void *p) { free(p); }
+
+int ntsm_host_format_counts(const ntsm_sites *s, const uint64_t *counts, uint64_t total_kmers, char **out, size_t *len)
+{
+	std::ostringstream os;
+	std::vector<uint64_t> c(counts, counts + s->set.keys.size());
+	ntsm::print_optional_header(os, total_kmers, s->set.k);
+	const bool ok = ntsm::print_counts_max(os, s->set, c);
+	*out = dup_string(os.str(), len);
+	return ok ? 0 : 1;
+}
+
+int ntsm_host_format_summary(const ntsm_sites *s, const uint64_t *counts, uint64_t total_bases, uint64_t total_kmers,
+		uint64_t total_hits, char **out, size_t *len, uint64_t *covered)
+{
+	std::vector<uint64_t> c(counts, counts + s->set.keys.size());
+	*out = dup_string(ntsm::info_summary(s->set, c, total_bases, total_kmers, total_hits), len);
+	if (covered) *covered = ntsm::sites_covered(s->set, c);
+	return 0;
+}
+
+} // extern "C"

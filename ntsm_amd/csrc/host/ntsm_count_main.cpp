@@ -1,0 +1,137 @@
+/*
+ * ntsmCount -- same command line and outputs as the reference tool (src/ntSeqMatchCount.cpp:53-185):
+ *   ntsmCount -s sites.fa [-t N] [-m COV] [-o summary] [-d] [-k K] [-v] reads.fq[.gz] ... > counts.txt
+ * stdout: "#@TK", "#@KS" headers + one row per site (countAT/countCG = max per-k-mer count of the
+ * allele).  stderr: collision warnings, the six summary lines, "Time: .. s Memory: .. kbytes".
+ * New, optional: -g/--gpu INT selects the HIP device (default 0).
+ */
+#include <getopt.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "fingerprint.hpp"
+
+#define PROGRAM "ntsmCount"
+
+static bool fexists(const std::string &fn) { std::ifstream f(fn.c_str()); return f.good(); }   /* src/Util.h:24-29 */
+
+static size_t rss_kb()                                  /* src/Util.h:32-49 */
+{
+	std::ifstream f("/proc/self/status");
+	std::string line;
+	while (std::getline(f, line))
+		if (line.compare(0, 6, "VmRSS:") == 0) return (size_t) strtoull(line.c_str() + 6, nullptr, 10);
+	return 0;
+}
+
+static void printVersion()
+{
+	std::cerr << PROGRAM " (ntsm-mi355x) " << ntsm_version() << "\n"
+	          << "MI355X-native implementation of the ntsmCount k-mer counting path\n" << std::endl;
+	exit(EXIT_SUCCESS);
+}
+
+static void printHelpDialog()
+{
+	static const char dialog[] =
+		"Usage: " PROGRAM " -s [FASTA] [OPTION]... [FILES...]\n"
+		"  -t, --threads = INT    Number of threads to run.[1]\n"
+		"  -m, --maxCov = INT     k-mer coverage threshold for early\n"
+		"                         termination. [inf]\n"
+		"  -o, --output = STR     Output for summary file.\n"
+		"  -d, --dupes            Allow shared k-mers between sites to\n"
+		"                         be counted.\n"
+		"  -s, --snp = STR        Interleaved fasta of SNP sites to\n"
+		"                         k-merize. [required]\n"
+		"  -k, --kmer = INT       k-mer size used. [19]\n"
+		"  -g, --gpu = INT        HIP device to run on. [0]\n"
+		"  -h, --help             Display this dialog.\n"
+		"  -v, --verbose          Display verbose output.\n"
+		"      --version          Print version information.\n";
+	std::cerr << dialog << std::endl;
+	exit(EXIT_SUCCESS);
+}
+
+template <class T>
+static bool parse(const char *arg, T &out)
+{
+	std::stringstream convert(arg);
+	return (bool) (convert >> out);
+}
+
+int main(int argc, char *argv[])
+{
+	ntsm::Options opt;
+	bool die = false;
+	int OPT_VERSION = 0;
+	/* "dupes" takes an argument in its long form only, as in the reference (:66 vs :75) */
+	static struct option long_options[] = {
+		{ "threads", required_argument, NULL, 't' }, { "maxCov", required_argument, NULL, 'm' },
+		{ "output", required_argument, NULL, 'o' },  { "dupes", required_argument, NULL, 'd' },
+		{ "snp", required_argument, NULL, 's' },     { "kmer", required_argument, NULL, 'k' },
+		{ "gpu", required_argument, NULL, 'g' },     { "help", no_argument, NULL, 'h' },
+		{ "version", no_argument, &OPT_VERSION, 1 }, { "verbose", no_argument, NULL, 'v' },
+		{ NULL, 0, NULL, 0 } };
+	int c, option_index = 0;
+	while ((c = getopt_long(argc, argv, "s:t:vhk:m:do:g:", long_options, &option_index)) != -1) {
+		switch (c) {
+		case 'h': printHelpDialog(); break;
+		case 'o': if (!parse(optarg, opt.summary)) { std::cerr << "Error - Invalid parameter o: " << optarg << std::endl; return 0; } break;
+		case 'd': opt.dupes = true; break;
+		case 's': if (!parse(optarg, opt.snp)) { std::cerr << "Error - Invalid parameter s: " << optarg << std::endl; return 0; } break;
+		case 'm': if (!parse(optarg, opt.covThresh)) { std::cerr << "Error - Invalid parameter m: " << optarg << std::endl; return 0; } break;
+		case 'k': if (!parse(optarg, opt.k)) { std::cerr << "Error - Invalid parameter k: " << optarg << std::endl; return 0; } break;
+		case 't': if (!parse(optarg, opt.threads)) { std::cerr << "Error - Invalid parameter t: " << optarg << std::endl; return 0; } break;
+		case 'g': if (!parse(optarg, opt.device)) { std::cerr << "Error - Invalid parameter g: " << optarg << std::endl; return 0; } break;
+		case 'v': opt.verbose++; break;
+		case '?': die = true; break;
+		}
+	}
+	if (OPT_VERSION) printVersion();
+	if (opt.k > 32) {
+		die = true;
+		std::cerr << "Error: k cannot be greater than 32" << std::endl;
+	}
+	if (opt.k == 0) {
+		die = true;
+		std::cerr << "Error: k must be at least 1" << std::endl;
+	}
+	if (opt.snp.empty()) {
+		die = true;
+		std::cerr << "Error: Missing variants (-s) file" << std::endl;
+	}
+	std::vector<std::string> inputFiles;
+	while (optind < argc) {
+		inputFiles.emplace_back(argv[optind]);
+		if (!fexists(inputFiles.back())) {             /* the reference asserts here (:160) */
+			std::cerr << PROGRAM ": input file " << inputFiles.back() << " does not exist" << std::endl;
+			abort();
+		}
+		optind++;
+	}
+	if (inputFiles.size() == 0) {
+		std::cerr << "Error: Need input files" << std::endl;
+		die = true;
+	}
+	if (die) {
+		std::cerr << "Try '--help' for more information.\n";
+		exit(EXIT_FAILURE);
+	}
+	if (const char *bb = getenv("NTSM_BATCH_BYTES")) opt.batch_bytes = strtoull(bb, nullptr, 10);   /* staging slot size */
+	const auto t0 = std::chrono::steady_clock::now();
+	ntsm::FingerPrint fp(opt);
+	fp.computeCounts(inputFiles);
+	fp.printOptionalHeader(std::cout);
+	fp.printCountsMax(std::cout);
+	std::cerr << fp.printInfoSummary() << std::endl;
+	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	std::cerr << "Time: " << secs << " s Memory: " << rss_kb() << " kbytes" << std::endl;
+	return 0;
+}

@@ -1,0 +1,60 @@
+/*
+ * seq_reader.hpp -- streaming FASTA/FASTQ record reader over zlib (plain or gzip input).
+ *
+ * Host-side replacement for the reference's kseq parser as ntsmCount uses it
+ * (vendor/kseq.h:177-219 instantiated over gzread at src/FingerPrint.hpp:27).  Record boundaries
+ * and sequence bytes must match it exactly because every byte of seq.s reaches the k-mer window
+ * (invalid bytes reset it and still count in "Total Bases Considered").  Behaviours kept:
+ *   - the first header is searched for anywhere ('>' or '@'), later ones only at a line start;
+ *   - name = header up to the first isspace() byte; the rest of the line is ignored;
+ *   - sequence lines are concatenated until a line starts with '>', '@' or '+'; empty lines are
+ *     skipped; one trailing '\r' per line is dropped only when the sequence so far is longer than
+ *     one byte; any other byte (spaces, digits, high bytes) is sequence;
+ *   - after '+': quality lines are consumed until their total length reaches the sequence length;
+ *     a length mismatch or a missing quality block ends the FILE (negative return), exactly like
+ *     the reference's `while (l >= 0 ...)` loop (src/FingerPrint.hpp:66-69).
+ */
+#ifndef NTSM_SEQ_READER_HPP
+#define NTSM_SEQ_READER_HPP
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <zlib.h>
+
+namespace ntsm {
+
+class SeqReader {
+public:
+	SeqReader() = default;
+	~SeqReader() { close(); }
+	SeqReader(const SeqReader &) = delete;
+	SeqReader &operator=(const SeqReader &) = delete;
+
+	bool open(const std::string &path);
+	void close();
+	/* Next record: returns the sequence length (>= 0), -1 at end of file, -2 on a truncated
+	 * quality block, -3 on a stream error.  seq()/name() are valid until the next call. */
+	int64_t next();
+	const std::vector<char> &seq() const { return seq_; }
+	const std::string &name() const { return name_; }
+
+private:
+	static constexpr int kBuf = 1 << 18;
+	int get();                                           /* next byte, -1 EOF, -3 error */
+	/* append bytes up to (not including) the next '\n' (line = true) or isspace byte to dst;
+	 * returns <0 exactly when the reference's ks_getuntil2 would; *delim = byte that stopped it */
+	int64_t until(bool line, std::vector<char> &dst, int *delim);
+	bool refill();                                       /* false at EOF/error */
+
+	gzFile f_ = nullptr;
+	std::vector<unsigned char> buf_;
+	int beg_ = 0, end_ = 0;
+	bool eof_ = false;
+	int pending_ = 0;                                    /* header byte already consumed ('>' / '@'), 0 = none */
+	std::vector<char> seq_, qual_, scratch_;
+	std::string name_;
+	uint64_t qual_len_ = 0;
+};
+
+} // namespace ntsm
+#endif

@@ -1,0 +1,57 @@
+/*
+ * ntsm_device.h -- data layout and hash functions shared by the host table builder and the
+ * gfx950 kernels (ntsm_hip.hip).
+ *
+ * HBM layout of one context:
+ *   filter      : 2^F bits (uint32 words); bit f(x) set for every site k-mer x.  Sized to stay in
+ *                 the 4 MiB per-XCD L2 (default F = 24 -> 2 MiB): >90 % of read k-mers end here.
+ *   keys        : 2-choice cuckoo table, 2^B buckets of two uint64 slots (16 B, one dwordx4 load);
+ *                 a site k-mer lives in bucket b1(x) or b2(x); empty slot = ~0.
+ *   slot_counts : uint64 per slot, bumped with one no-return 64-bit atomic per hit.
+ *   slot_of     : uint32 per site k-mer (dense index -> slot) for the final gather.
+ * Keys are the reference's canonical codes (vendor/KseqHashIterator.hpp:99-104); bucket hashes
+ * are free to choose because the reference's hash64 is a bijection (results depend only on set
+ * membership of the canonical code).
+ */
+#ifndef NTSM_DEVICE_H
+#define NTSM_DEVICE_H
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NTSM_DHD __host__ __device__ __forceinline__
+#else
+#define NTSM_DHD static inline
+#endif
+
+#define NTSM_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
+
+/* 32-bit mixes of a canonical code (2k <= 64 bits). */
+NTSM_DHD uint32_t ntsm_fold(uint64_t x)
+{
+	return (uint32_t) x ^ ((uint32_t) (x >> 32) * 0x85EBCA6Bu);
+}
+NTSM_DHD uint32_t ntsm_h1(uint32_t folded) { return folded * 0x9E3779B1u; }
+NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC2B2AE35u + 0x27D4EB2Fu; }
+
+struct NtsmCountParams {
+	const uint8_t *base;               /* 16-byte aligned start of the flat stream */
+	long long lo, hi;                  /* count windows ending at byte offsets in [lo, hi) */
+	long long t0;                      /* tile origin (multiple of 16, <= lo) */
+	unsigned long long n_tiles;
+	const uint32_t *filter;
+	const uint64_t *keys;
+	unsigned long long *slot_counts;
+	unsigned long long *totals;        /* [0] k-mers, [1] hits */
+	const unsigned long long *read_end;/* per-read attribution (early-stop mode only) */
+	uint32_t *read_hits;
+	unsigned long long n_reads;
+	unsigned long long sign;           /* +1 or 2^64-1 */
+	unsigned long long mask;           /* (1 << 2k) - 1 */
+	uint32_t k, rv_shift;              /* 2(k-1) */
+	uint32_t kmask;                    /* low k bits set: window validity */
+	uint32_t fshift, bshift;           /* bit index = h1 >> fshift ; bucket = h >> bshift */
+	const uint8_t *lut;                /* 256-byte base table, vendor/KseqHashIterator.hpp:114-127 */
+};
+
+#endif

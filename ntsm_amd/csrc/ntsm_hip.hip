@@ -1,0 +1,927 @@
+/*
+ * ntsm_hip.hip -- gfx950 kernels + the C ABI of include/ntsm_hip.h.
+ *
+ * Replaces the inner loop of the reference's FingerPrint::insertCount
+ * (src/FingerPrint.hpp:89-103): KseqHashIterator's rolling 2-bit canonical k-mer
+ * (vendor/KseqHashIterator.hpp:95-112), the tsl::robin_map lookup (src/FingerPrint.hpp:92) and
+ * the `+= 1` (src/FingerPrint.hpp:94-99), batched over a flat stream of reads.
+ *
+ * Kernel structure (wave64, integer only, no MFMA -- DESIGN.md section 4):
+ *   - a workgroup of 256 threads owns a tile of 256*C contiguous stream bytes; the tile is staged
+ *     through LDS with coalesced 16-byte loads, rows padded by 16 B so that the per-thread
+ *     ds_read_b128 of its own C-byte chunk is bank-conflict free;
+ *   - each thread rolls fw / rc codes over its chunk (after warming up on the 32 bytes before it)
+ *     and keeps a shift register of "invalid base" flags, so window validity is purely local and
+ *     no k-mer can span the 'N' terminator between reads;
+ *   - every valid window probes a 1-bit filter (L2 resident); the rare positives read their two
+ *     16-byte cuckoo buckets and bump a 64-bit counter with one no-return atomic.
+ * There is no CPU fallback anywhere in this file.
+ */
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ntsm_hip.h"
+#include "ntsm_device.h"
+
+/* ============================================================================================
+ * Device code
+ * ========================================================================================== */
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint32_t kN4 = 0x4E4E4E4Eu;      /* "NNNN" */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint4 ntsm_load_vec(const NtsmCountParams &p, long long o)
+{
+	uint4 r = make_uint4(kN4, kN4, kN4, kN4);
+	if (o + 16 > p.lo && o < p.hi) {
+		const u32x4 nt = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p.base + o));
+		r = make_uint4(nt.x, nt.y, nt.z, nt.w);
+		if (o < p.lo || o + 16 > p.hi) {                    /* first / last vector of the range */
+			uint32_t w[4] = { r.x, r.y, r.z, r.w };
+			for (int b = 0; b < 16; ++b) {
+				long long pos = o + b;
+				if (pos < p.lo || pos >= p.hi)
+					w[b >> 2] = (w[b >> 2] & ~(0xFFu << ((b & 3) * 8))) | (0x4Eu << ((b & 3) * 8));
+			}
+			r = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+	}
+	return r;
+}
+
+/* first read whose terminator lies beyond byte offset pos */
+__device__ __forceinline__ unsigned long long ntsm_read_of(const NtsmCountParams &p, unsigned long long pos)
+{
+	unsigned long long lo = 0, hi = p.n_reads;
+	while (lo < hi) {
+		unsigned long long mid = (lo + hi) >> 1;
+		if (p.read_end[mid] > pos) hi = mid; else lo = mid + 1;
+	}
+	return lo;
+}
+
+template <int C, bool PER_READ>
+__global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountParams p)
+{
+	constexpr int ROW = C + 16;
+	constexpr int VPT = C / 16;                              /* vectors per thread */
+	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * ROW];
+	__shared__ uint8_t lut[256];
+	const int t = threadIdx.x;
+	lut[t] = p.lut[t];
+
+	const unsigned long long mask = p.mask;
+	const uint32_t rv_shift = p.rv_shift, kmask = p.kmask, fshift = p.fshift, bshift = p.bshift;
+	uint32_t nk = 0, nh = 0;
+
+	for (unsigned long long ti = blockIdx.x; ti < p.n_tiles; ti += gridDim.x) {
+		const long long ts = p.t0 + (long long) (ti * (unsigned long long) (kThreads * C));
+		__syncthreads();                                     /* previous tile fully consumed */
+#pragma unroll
+		for (int q = 0; q < VPT; ++q) {
+			const int v = t + kThreads * q;
+			const uint4 r = ntsm_load_vec(p, ts + 16ll * v);
+			const int row = 1 + (16 * v) / C, col = (16 * v) % C;
+			*reinterpret_cast<uint4 *>(tile + row * ROW + col) = r;
+		}
+		if (t < 2) {
+			const uint4 r = ntsm_load_vec(p, ts - 32 + 16 * t);
+			*reinterpret_cast<uint4 *>(tile + (C - 32) + 16 * t) = r;
+		}
+		__syncthreads();
+
+		unsigned long long fw = 0, rv = 0;
+		uint32_t inv = 0xFFFFFFFFu;
+#define NTSM_ROLL(byte_)                                                                  \
+		{                                                                                 \
+			const uint32_t code_ = lut[(byte_)];                                          \
+			const unsigned long long c_ = code_ & 3u;                                     \
+			fw = ((fw << 2) | c_) & mask;                                                 \
+			rv = (rv >> 2) | ((3ull - c_) << rv_shift);                                   \
+			inv = (inv << 1) | (code_ >> 2);                                              \
+		}
+		{   /* warm-up on the 32 bytes in front of this thread's chunk (k - 1 <= 31 needed) */
+			const uint8_t *prev = tile + t * ROW + (C - 32);
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const uint4 v = *reinterpret_cast<const uint4 *>(prev + 16 * h);
+				const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+				for (int i = 0; i < 16; ++i) NTSM_ROLL((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu)
+			}
+		}
+		const uint8_t *own = tile + (t + 1) * ROW;
+		for (int g = 0; g < VPT; ++g) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(own + 16 * g);
+			const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+			unsigned long long cn[16];
+			uint32_t hh[16], fwd[16];
+			bool ok[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				NTSM_ROLL((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu)
+				ok[i] = (inv & kmask) == 0;
+				cn[i] = fw < rv ? fw : rv;
+				hh[i] = ntsm_fold(cn[i]);
+				const uint32_t bit = ntsm_h1(hh[i]) >> fshift;
+				fwd[i] = p.filter[bit >> 5];                 /* always in range: unconditional, keeps 16 loads in flight */
+			}
+#pragma unroll
+			for (int s = 0; s < 4; ++s) {
+				uint4 ba[4], bb[4];
+				bool pos[4];
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const int i = 4 * s + j;
+					const uint32_t h1 = ntsm_h1(hh[i]);
+					nk += ok[i] ? 1u : 0u;
+					pos[j] = ok[i] && ((fwd[i] >> ((h1 >> fshift) & 31u)) & 1u);
+					if (pos[j]) {
+						ba[j] = *reinterpret_cast<const uint4 *>(p.keys + 2ull * (h1 >> bshift));
+						bb[j] = *reinterpret_cast<const uint4 *>(p.keys + 2ull * (ntsm_h2(hh[i]) >> bshift));
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const int i = 4 * s + j;
+					if (pos[j]) {
+						const uint32_t klo = (uint32_t) cn[i], khi = (uint32_t) (cn[i] >> 32);
+						const unsigned long long b1 = 2ull * (ntsm_h1(hh[i]) >> bshift);
+						const unsigned long long b2 = 2ull * (ntsm_h2(hh[i]) >> bshift);
+						long long slot = -1;
+						if (ba[j].x == klo && ba[j].y == khi) slot = (long long) b1;
+						else if (ba[j].z == klo && ba[j].w == khi) slot = (long long) b1 + 1;
+						else if (bb[j].x == klo && bb[j].y == khi) slot = (long long) b2;
+						else if (bb[j].z == klo && bb[j].w == khi) slot = (long long) b2 + 1;
+						if (slot >= 0) {
+							__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							++nh;
+							if (PER_READ) {
+								const unsigned long long pb = (unsigned long long) (ts + (long long) t * C + 16 * g + i);
+								atomicAdd(p.read_hits + ntsm_read_of(p, pb), 1u);
+							}
+						}
+					}
+				}
+			}
+		}
+#undef NTSM_ROLL
+	}
+	/* per-wave reduction, one 64-bit atomic per wave and counter */
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		nk += __shfl_down(nk, off, 64);
+		nh += __shfl_down(nh, off, 64);
+	}
+	if ((t & 63) == 0) {
+		if (nk) atomicAdd(p.totals + 0, p.sign * (unsigned long long) nk);
+		if (nh) atomicAdd(p.totals + 1, p.sign * (unsigned long long) nh);
+	}
+}
+
+/* dense[i] = slot_counts[slot_of[i]]; tail = totals */
+__global__ void ntsm_gather_kernel(const unsigned long long *slot_counts, const uint32_t *slot_of,
+		uint32_t n, unsigned long long *dense)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		dense[i] = slot_counts[slot_of[i]];
+}
+
+} // namespace
+
+/* ============================================================================================
+ * Host code: context, table build, batching, C ABI
+ * ========================================================================================== */
+
+static thread_local int g_last_hip = 0;
+
+#define HIPCHK(call)                                                                      \
+	do {                                                                                  \
+		hipError_t e_ = (call);                                                           \
+		if (e_ != hipSuccess) {                                                           \
+			g_last_hip = (int) e_;                                                        \
+			fprintf(stderr, "ntsm_hip: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return NTSM_ERR_HIP;                                                          \
+		}                                                                                 \
+	} while (0)
+
+namespace {
+
+constexpr int kTileC = 128;                 /* stream bytes per thread and tile */
+constexpr int kTimingPool = 256;
+
+struct Slot {
+	uint8_t *h_bases = nullptr, *d_bases = nullptr;
+	uint64_t *h_read_end = nullptr, *d_read_end = nullptr;
+	hipStream_t stream = nullptr;
+	hipEvent_t done = nullptr;                 /* last use of the host buffer finished */
+	bool busy = false, acquired = false;
+};
+
+/* vendor/KseqHashIterator.hpp:114-127 restated as data for the kernel's LDS table */
+void build_lut(uint8_t *lut)
+{
+	for (int i = 0; i < 256; ++i) lut[i] = 4;
+	for (int i = 0; i < 4; ++i) lut[i] = (uint8_t) i;
+	lut['A'] = lut['a'] = 0;
+	lut['C'] = lut['c'] = 1;
+	lut['G'] = lut['g'] = 2;
+	lut['T'] = lut['t'] = lut['U'] = lut['u'] = 3;
+}
+
+uint64_t mask_for_k(int k) { return k >= 32 ? 0ull : ((1ull << (2 * k)) - 1); }   /* k = 32: see header */
+
+uint64_t inv_odd(uint64_t a)                 /* multiplicative inverse mod 2^64 */
+{
+	uint64_t x = a;
+	for (int i = 0; i < 6; ++i) x *= 2 - a * x;
+	return x;
+}
+
+uint64_t unxorshift(uint64_t y, int s)
+{
+	for (int sh = s; sh < 64; sh *= 2) y ^= y >> sh;
+	return y;
+}
+
+} // namespace
+
+struct ntsm_ctx {
+	int device = 0, k = 0;
+	uint32_t n_kmers = 0;
+	uint64_t max_hits = 0;
+	uint64_t mask = 0;
+	/* device tables */
+	uint32_t *d_filter = nullptr, *d_slot_of = nullptr, *d_read_hits = nullptr;
+	uint64_t *d_keys = nullptr;
+	unsigned long long *d_slot_counts = nullptr, *d_totals = nullptr, *d_vec = nullptr;
+	uint8_t *d_lut = nullptr;
+	uint32_t filter_log2 = 0, bucket_log2 = 0;
+	uint64_t n_slots = 0;
+	std::vector<uint64_t> canon;               /* host copy of the canonical keys */
+	std::vector<uint32_t> slot_of;
+	/* batching */
+	Slot slot[2];
+	int next_slot = 0;
+	uint64_t cap_bytes = 64ull << 20, cap_reads = 1ull << 20;
+	hipStream_t rstream = nullptr;             /* stream for resident batches */
+	/* host-side totals */
+	uint64_t total_bases = 0, reads_consumed = 0;
+	bool early_stop = false, reduced = false;
+	uint64_t red_totals[4] = { 0, 0, 0, 0 };
+	/* tuning / timing */
+	int grid_blocks = 0, n_cu = 256;
+	bool timing = false;
+	hipEvent_t ev_a[kTimingPool], ev_b[kTimingPool];
+	bool ev_used[kTimingPool];
+	int ev_next = 0;
+	uint64_t t_launches = 0;
+	double t_ms = 0;
+};
+
+namespace {
+
+int build_tables(ntsm_ctx *c, int filter_log2_req)
+{
+	const uint32_t n = c->n_kmers;
+	/* slots: power of two with load <= 0.4; at least 32 */
+	uint64_t slots = 32;
+	while ((double) n > 0.4 * (double) slots) slots <<= 1;
+	std::vector<uint64_t> keys;
+	for (;; slots <<= 1) {
+		const uint32_t blog = (uint32_t) __builtin_ctzll(slots >> 1);
+		const uint32_t bshift = 32 - blog;
+		keys.assign(slots, NTSM_EMPTY_KEY);
+		c->slot_of.assign(n, 0);
+		std::vector<uint32_t> owner(slots, 0);            /* dense index stored in each slot */
+		bool ok = true;
+		uint64_t rng = 0x9E3779B97F4A7C15ull;
+		for (uint32_t i = 0; i < n && ok; ++i) {
+			uint64_t key = c->canon[i];
+			uint32_t idx = i;
+			/* duplicate check against both candidate buckets */
+			{
+				const uint32_t f = ntsm_fold(key);
+				const uint64_t b[2] = { 2ull * (ntsm_h1(f) >> bshift), 2ull * (ntsm_h2(f) >> bshift) };
+				for (int q = 0; q < 2; ++q)
+					for (int s = 0; s < 2; ++s)
+						if (keys[b[q] + s] == key) return NTSM_ERR_DUP_KEY;
+			}
+			bool placed = false;
+			for (int kick = 0; kick < 1000 && !placed; ++kick) {
+				const uint32_t f = ntsm_fold(key);
+				const uint64_t b[2] = { 2ull * (ntsm_h1(f) >> bshift), 2ull * (ntsm_h2(f) >> bshift) };
+				for (int q = 0; q < 2 && !placed; ++q)
+					for (int s = 0; s < 2 && !placed; ++s)
+						if (keys[b[q] + s] == NTSM_EMPTY_KEY) {
+							keys[b[q] + s] = key;
+							owner[b[q] + s] = idx;
+							placed = true;
+						}
+				if (placed) break;
+				rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+				const uint64_t victim = b[(rng >> 33) & 1] + ((rng >> 34) & 1);
+				std::swap(key, keys[victim]);
+				std::swap(idx, owner[victim]);
+			}
+			if (!placed) ok = false;
+		}
+		if (!ok) continue;                                /* grow and retry */
+		for (uint64_t s = 0; s < slots; ++s)
+			if (keys[s] != NTSM_EMPTY_KEY) c->slot_of[owner[s]] = (uint32_t) s;
+		c->n_slots = slots;
+		c->bucket_log2 = blog;
+		break;
+	}
+	/* filter: >= 8 bits per key, 2^16 .. 2^28 bits; F = 24 (2 MiB) for the 1.5 M-key human set */
+	uint32_t flog = 16;
+	while (flog < 28 && (1ull << flog) < 8ull * n) ++flog;
+	if (filter_log2_req >= 10 && filter_log2_req <= 30) flog = (uint32_t) filter_log2_req;
+	c->filter_log2 = flog;
+	std::vector<uint32_t> filter((1ull << flog) / 32, 0);
+	const uint32_t fshift = 32 - flog;
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint32_t bit = ntsm_h1(ntsm_fold(c->canon[i])) >> fshift;
+		filter[bit >> 5] |= 1u << (bit & 31);
+	}
+	/* upload */
+	if (c->d_filter) (void) hipFree(c->d_filter);
+	if (c->d_keys) (void) hipFree(c->d_keys);
+	if (c->d_slot_counts) (void) hipFree(c->d_slot_counts);
+	if (c->d_slot_of) (void) hipFree(c->d_slot_of);
+	c->d_filter = nullptr; c->d_keys = nullptr; c->d_slot_counts = nullptr; c->d_slot_of = nullptr;
+	HIPCHK(hipMalloc(&c->d_filter, filter.size() * sizeof(uint32_t)));
+	HIPCHK(hipMalloc(&c->d_keys, c->n_slots * sizeof(uint64_t)));
+	HIPCHK(hipMalloc(&c->d_slot_counts, c->n_slots * sizeof(uint64_t)));
+	HIPCHK(hipMalloc(&c->d_slot_of, (n ? n : 1) * sizeof(uint32_t)));
+	HIPCHK(hipMemcpy(c->d_filter, filter.data(), filter.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(c->d_keys, keys.data(), c->n_slots * sizeof(uint64_t), hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(c->d_slot_counts, 0, c->n_slots * sizeof(uint64_t)));
+	if (n) HIPCHK(hipMemcpy(c->d_slot_of, c->slot_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	return NTSM_OK;
+}
+
+int alloc_slot(ntsm_ctx *c, Slot &s)
+{
+	HIPCHK(hipHostMalloc(&s.h_bases, c->cap_bytes + 64, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc(&s.h_read_end, c->cap_reads * sizeof(uint64_t), hipHostMallocDefault));
+	HIPCHK(hipMalloc(&s.d_bases, c->cap_bytes + 64));
+	HIPCHK(hipMalloc(&s.d_read_end, c->cap_reads * sizeof(uint64_t)));
+	if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+	if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+	s.busy = false;
+	s.acquired = false;
+	return NTSM_OK;
+}
+
+void free_slot(Slot &s)
+{
+	if (s.h_bases) (void) hipHostFree(s.h_bases);
+	if (s.h_read_end) (void) hipHostFree(s.h_read_end);
+	if (s.d_bases) (void) hipFree(s.d_bases);
+	if (s.d_read_end) (void) hipFree(s.d_read_end);
+	s.h_bases = s.d_bases = nullptr;
+	s.h_read_end = s.d_read_end = nullptr;
+}
+
+/* launch one count pass over stream bytes [lo, hi) of d_bases */
+int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t lo, uint64_t hi,
+		const uint64_t *d_read_end, uint64_t n_reads, bool per_read, int sign)
+{
+	if (hi <= lo) return NTSM_OK;
+	NtsmCountParams p;
+	memset(&p, 0, sizeof p);
+	p.base = d_bases;
+	p.lo = (long long) lo;
+	p.hi = (long long) hi;
+	p.t0 = (long long) (lo & ~15ull);
+	const uint64_t tile = (uint64_t) kThreads * kTileC;
+	p.n_tiles = (hi - (uint64_t) p.t0 + tile - 1) / tile;
+	p.filter = c->d_filter;
+	p.keys = c->d_keys;
+	p.slot_counts = c->d_slot_counts;
+	p.totals = c->d_totals;
+	p.read_end = (const unsigned long long *) d_read_end;
+	p.read_hits = c->d_read_hits;
+	p.n_reads = n_reads;
+	p.sign = sign >= 0 ? 1ull : ~0ull;
+	p.mask = c->mask;
+	p.k = (uint32_t) c->k;
+	p.rv_shift = (uint32_t) (2 * (c->k - 1));
+	p.kmask = c->k >= 32 ? 0xFFFFFFFFu : ((1u << c->k) - 1);
+	p.fshift = 32 - c->filter_log2;
+	p.bshift = 32 - c->bucket_log2;
+	p.lut = c->d_lut;
+	uint64_t grid = c->grid_blocks > 0 ? (uint64_t) c->grid_blocks : (uint64_t) c->n_cu * 4;
+	if (grid > p.n_tiles) grid = p.n_tiles;
+	int ev = -1;
+	if (c->timing) {
+		ev = c->ev_next;
+		c->ev_next = (c->ev_next + 1) % kTimingPool;
+		if (c->ev_used[ev]) {                             /* recycle: fold the old measurement in */
+			float ms = 0;
+			HIPCHK(hipEventSynchronize(c->ev_b[ev]));
+			HIPCHK(hipEventElapsedTime(&ms, c->ev_a[ev], c->ev_b[ev]));
+			c->t_ms += ms;
+			c->ev_used[ev] = false;
+		}
+		HIPCHK(hipEventRecord(c->ev_a[ev], st));
+	}
+	if (per_read)
+		hipLaunchKernelGGL((ntsm_count_kernel<kTileC, true>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
+	else
+		hipLaunchKernelGGL((ntsm_count_kernel<kTileC, false>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
+	HIPCHK(hipGetLastError());
+	if (ev >= 0) {
+		HIPCHK(hipEventRecord(c->ev_b[ev], st));
+		c->ev_used[ev] = true;
+		c->t_launches++;
+	}
+	return NTSM_OK;
+}
+
+int read_device_totals(ntsm_ctx *c, uint64_t out[2])
+{
+	HIPCHK(hipMemcpy(out, c->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	return NTSM_OK;
+}
+
+/* Early-stop ("-m") batch: count with per-read attribution, then, if the running hit total
+ * crossed max_hits inside this batch, find the first read r* after which total_hits > max_hits
+ * (src/FingerPrint.hpp:476-487: checked after each whole read, strict '>') and take the reads
+ * after r* out again with a sign = -1 pass.  d_read_end must be on the device. */
+int armed_batch(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t n_bytes,
+		const uint64_t *d_read_end, const uint64_t *h_read_end_or_null, uint64_t n_reads)
+{
+	uint64_t before[2];
+	HIPCHK(hipStreamSynchronize(st));
+	int rc = read_device_totals(c, before);
+	if (rc) return rc;
+	if (n_reads > c->cap_reads && c->d_read_hits) { (void) hipFree(c->d_read_hits); c->d_read_hits = nullptr; }
+	if (!c->d_read_hits) {
+		const uint64_t cap = n_reads > c->cap_reads ? n_reads : c->cap_reads;
+		HIPCHK(hipMalloc(&c->d_read_hits, cap * sizeof(uint32_t)));
+		if (n_reads > c->cap_reads) c->cap_reads = n_reads;
+	}
+	HIPCHK(hipMemsetAsync(c->d_read_hits, 0, n_reads * sizeof(uint32_t), st));
+	rc = launch_count(c, st, d_bases, 0, n_bytes, d_read_end, n_reads, true, +1);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(st));
+	uint64_t after[2];
+	rc = read_device_totals(c, after);
+	if (rc) return rc;
+	std::vector<uint64_t> re_local;
+	const uint64_t *re = h_read_end_or_null;
+	if (after[1] <= c->max_hits) {                        /* no crossing in this batch */
+		if (!re) {
+			uint64_t last = 0;
+			HIPCHK(hipMemcpy(&last, d_read_end + (n_reads - 1), sizeof last, hipMemcpyDeviceToHost));
+			c->total_bases += last + 1 - n_reads;
+		} else {
+			c->total_bases += re[n_reads - 1] + 1 - n_reads;
+		}
+		c->reads_consumed += n_reads;
+		return NTSM_OK;
+	}
+	std::vector<uint32_t> hits(n_reads);
+	HIPCHK(hipMemcpy(hits.data(), c->d_read_hits, n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	if (!re) {
+		re_local.resize(n_reads);
+		HIPCHK(hipMemcpy(re_local.data(), d_read_end, n_reads * sizeof(uint64_t), hipMemcpyDeviceToHost));
+		re = re_local.data();
+	}
+	uint64_t run = before[1], rstar = n_reads - 1;
+	for (uint64_t r = 0; r < n_reads; ++r) {
+		run += hits[r];
+		if (run > c->max_hits) { rstar = r; break; }
+	}
+	rc = launch_count(c, st, d_bases, re[rstar] + 1, n_bytes, nullptr, 0, false, -1);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(st));
+	c->total_bases += re[rstar] + 1 - (rstar + 1);
+	c->reads_consumed += rstar + 1;
+	c->early_stop = true;
+	return NTSM_OK;
+}
+
+int check_layout(const uint64_t *read_end, uint32_t n_reads, uint64_t n_bytes)
+{
+	if (n_reads == 0) return n_bytes == 0 ? NTSM_OK : NTSM_ERR_ARG;
+	if (!read_end || read_end[n_reads - 1] + 1 != n_bytes) return NTSM_ERR_ARG;
+	return NTSM_OK;
+}
+
+int submit_slot(ntsm_ctx *c, Slot &s, uint64_t n_bytes, uint32_t n_reads)
+{
+	if (n_reads == 0) return NTSM_OK;
+	HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, n_bytes, hipMemcpyHostToDevice, s.stream));
+	if (c->max_hits) {
+		HIPCHK(hipMemcpyAsync(s.d_read_end, s.h_read_end, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+		return armed_batch(c, s.stream, s.d_bases, n_bytes, s.d_read_end, s.h_read_end, n_reads);
+	}
+	int rc = launch_count(c, s.stream, s.d_bases, 0, n_bytes, nullptr, 0, false, +1);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(s.done, s.stream));
+	s.busy = true;
+	c->total_bases += n_bytes - n_reads;
+	c->reads_consumed += n_reads;
+	return NTSM_OK;
+}
+
+int wait_slot(Slot &s)
+{
+	if (s.busy) {
+		HIPCHK(hipEventSynchronize(s.done));
+		s.busy = false;
+	}
+	return NTSM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint64_t ntsm_hash64(uint64_t key, int k)
+{
+	const uint64_t mask = mask_for_k(k);
+	key = (~key + (key << 21)) & mask;
+	key ^= key >> 24;
+	key = (key + (key << 3) + (key << 8)) & mask;
+	key ^= key >> 14;
+	key = (key + (key << 2) + (key << 4)) & mask;
+	key ^= key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+uint64_t ntsm_hash64_inv(uint64_t hv, int k)
+{
+	const uint64_t mask = mask_for_k(k);
+	uint64_t x = hv & mask;
+	x = (x * inv_odd((1ull << 31) + 1)) & mask;
+	x = unxorshift(x, 28);
+	x = (x * inv_odd(21)) & mask;
+	x = unxorshift(x, 14);
+	x = (x * inv_odd(265)) & mask;
+	x = unxorshift(x, 24);
+	x = ((x + 1) * inv_odd((1ull << 21) - 1)) & mask;
+	return x;
+}
+
+const char *ntsm_strerror(int code)
+{
+	switch (code) {
+	case NTSM_OK: return "ok";
+	case NTSM_ERR_ARG: return "invalid argument";
+	case NTSM_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+	case NTSM_ERR_HIP: return "HIP runtime error";
+	case NTSM_ERR_DUP_KEY: return "duplicate k-mer key";
+	case NTSM_ERR_NOMEM: return "out of memory";
+	case NTSM_ERR_STATE: return "invalid state for this call";
+	case NTSM_ERR_RCCL: return "RCCL error";
+	default: return "unknown error";
+	}
+}
+
+int ntsm_last_hip_error(void) { return g_last_hip; }
+const char *ntsm_version(void) { return "ntsm_hip 0.1 (gfx950)"; }
+
+int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_t n_kmers,
+		int key_kind, uint64_t max_hits)
+{
+	if (!out || k < 1 || k > 32 || (n_kmers && !keys)) return NTSM_ERR_ARG;
+	if (key_kind != NTSM_KEYS_CANONICAL && key_kind != NTSM_KEYS_HASH64) return NTSM_ERR_ARG;
+	*out = nullptr;
+	int n_dev = 0;
+	hipError_t e = hipGetDeviceCount(&n_dev);
+	if (e != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+		g_last_hip = (int) e;
+		return NTSM_ERR_NO_DEVICE;
+	}
+	HIPCHK(hipSetDevice(device));
+	ntsm_ctx *c = new (std::nothrow) ntsm_ctx();
+	if (!c) return NTSM_ERR_NOMEM;
+	c->device = device;
+	c->k = k;
+	c->n_kmers = n_kmers;
+	c->max_hits = max_hits;
+	c->mask = mask_for_k(k);
+	memset(c->ev_used, 0, sizeof c->ev_used);
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+		c->n_cu = prop.multiProcessorCount;
+	c->canon.resize(n_kmers);
+	for (uint32_t i = 0; i < n_kmers; ++i) {
+		uint64_t x = key_kind == NTSM_KEYS_HASH64 ? ntsm_hash64_inv(keys[i], k) : keys[i];
+		if (x & ~c->mask && k < 32) { delete c; return NTSM_ERR_ARG; }
+		c->canon[i] = x;
+	}
+	int rc = build_tables(c, 0);
+	if (rc) { ntsm_destroy(c); return rc; }
+	uint8_t lut[256];
+	build_lut(lut);
+	auto fail = [&](int code) { ntsm_destroy(c); return code; };
+	if (hipMalloc(&c->d_lut, 256) != hipSuccess) return fail(NTSM_ERR_HIP);
+	if (hipMemcpy(c->d_lut, lut, 256, hipMemcpyHostToDevice) != hipSuccess) return fail(NTSM_ERR_HIP);
+	if (hipMalloc(&c->d_totals, 4 * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
+	if (hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
+	if (hipMalloc(&c->d_vec, ((uint64_t) n_kmers + 4) * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
+	if (hipStreamCreateWithFlags(&c->rstream, hipStreamNonBlocking) != hipSuccess) return fail(NTSM_ERR_HIP);
+	for (int i = 0; i < kTimingPool; ++i) {
+		if (hipEventCreate(&c->ev_a[i]) != hipSuccess || hipEventCreate(&c->ev_b[i]) != hipSuccess) return fail(NTSM_ERR_HIP);
+	}
+	*out = c;
+	return NTSM_OK;
+}
+
+void ntsm_destroy(ntsm_ctx *c)
+{
+	if (!c) return;
+	(void) hipSetDevice(c->device);
+	(void) hipDeviceSynchronize();
+	for (auto &s : c->slot) {
+		free_slot(s);
+		if (s.stream) (void) hipStreamDestroy(s.stream);
+		if (s.done) (void) hipEventDestroy(s.done);
+	}
+	if (c->rstream) (void) hipStreamDestroy(c->rstream);
+	for (int i = 0; i < kTimingPool; ++i) {
+		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
+		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
+	}
+	void *ptrs[] = { c->d_filter, c->d_keys, c->d_slot_counts, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
+	for (void *p : ptrs) if (p) (void) hipFree(p);
+	delete c;
+}
+
+int ntsm_set_batch_capacity(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads)
+{
+	if (!c || cap_bytes < 4096 || cap_reads < 16) return NTSM_ERR_ARG;
+	HIPCHK(hipSetDevice(c->device));
+	for (auto &s : c->slot) {
+		int rc = wait_slot(s);
+		if (rc) return rc;
+		free_slot(s);
+	}
+	c->cap_bytes = cap_bytes;
+	c->cap_reads = cap_reads;
+	if (c->d_read_hits) { (void) hipFree(c->d_read_hits); c->d_read_hits = nullptr; }
+	return NTSM_OK;
+}
+
+int ntsm_staging_acquire(ntsm_ctx *c, uint8_t **bases, uint64_t *cap_bytes, uint64_t **read_end, uint64_t *cap_reads)
+{
+	if (!c || !bases || !cap_bytes || !read_end || !cap_reads) return NTSM_ERR_ARG;
+	HIPCHK(hipSetDevice(c->device));
+	Slot &s = c->slot[c->next_slot];
+	if (!s.h_bases) {
+		int rc = alloc_slot(c, s);
+		if (rc) return rc;
+	}
+	int rc = wait_slot(s);
+	if (rc) return rc;
+	s.acquired = true;
+	*bases = s.h_bases;
+	*cap_bytes = c->cap_bytes;
+	*read_end = s.h_read_end;
+	*cap_reads = c->cap_reads;
+	return NTSM_OK;
+}
+
+int ntsm_submit_staged(ntsm_ctx *c, uint64_t n_bytes, uint32_t n_reads)
+{
+	if (!c) return NTSM_ERR_ARG;
+	Slot &s = c->slot[c->next_slot];
+	if (!s.acquired) return NTSM_ERR_STATE;
+	s.acquired = false;
+	if (n_bytes > c->cap_bytes || n_reads > c->cap_reads) return NTSM_ERR_ARG;
+	int rc = check_layout(s.h_read_end, n_reads, n_bytes);
+	if (rc) return rc;
+	if (c->early_stop) return NTSM_OK;                    /* threshold already tripped: nothing more is counted */
+	c->reduced = false;
+	HIPCHK(hipSetDevice(c->device));
+	rc = submit_slot(c, s, n_bytes, n_reads);
+	c->next_slot ^= 1;
+	return rc;
+}
+
+int ntsm_submit(ntsm_ctx *c, const uint8_t *bases, uint64_t n_bytes, const uint64_t *read_end, uint32_t n_reads)
+{
+	if (!c || (n_bytes && !bases)) return NTSM_ERR_ARG;
+	int rc = check_layout(read_end, n_reads, n_bytes);
+	if (rc) return rc;
+	if (n_reads == 0) return NTSM_OK;
+	if (n_bytes > c->cap_bytes || n_reads > c->cap_reads) {
+		uint64_t nb = std::max(c->cap_bytes, n_bytes), nr = std::max<uint64_t>(c->cap_reads, n_reads);
+		rc = ntsm_set_batch_capacity(c, nb, nr);
+		if (rc) return rc;
+	}
+	uint8_t *hb; uint64_t cb, *hr, cr;
+	rc = ntsm_staging_acquire(c, &hb, &cb, &hr, &cr);
+	if (rc) return rc;
+	memcpy(hb, bases, n_bytes);
+	memcpy(hr, read_end, (size_t) n_reads * sizeof(uint64_t));
+	return ntsm_submit_staged(c, n_bytes, n_reads);
+}
+
+int ntsm_count_resident(ntsm_ctx *c, const void *d_bases, uint64_t n_bytes, const void *d_read_end, uint64_t n_reads, int sign)
+{
+	if (!c || (n_bytes && !d_bases) || (sign != 1 && sign != -1)) return NTSM_ERR_ARG;
+	if (((uintptr_t) d_bases & 15) != 0) return NTSM_ERR_ARG;
+	if (n_reads == 0 || n_bytes == 0) return NTSM_OK;
+	if (c->early_stop) return NTSM_OK;
+	c->reduced = false;
+	HIPCHK(hipSetDevice(c->device));
+	if (c->max_hits && sign > 0) {
+		if (!d_read_end) return NTSM_ERR_ARG;
+		return armed_batch(c, c->rstream, (const uint8_t *) d_bases, n_bytes, (const uint64_t *) d_read_end, nullptr, n_reads);
+	}
+	int rc = launch_count(c, c->rstream, (const uint8_t *) d_bases, 0, n_bytes, nullptr, 0, false, sign);
+	if (rc) return rc;
+	if (sign > 0) { c->total_bases += n_bytes - n_reads; c->reads_consumed += n_reads; }
+	else { c->total_bases -= n_bytes - n_reads; c->reads_consumed -= n_reads; }
+	return NTSM_OK;
+}
+
+int ntsm_sync(ntsm_ctx *c, ntsm_totals *t)
+{
+	if (!c) return NTSM_ERR_ARG;
+	HIPCHK(hipSetDevice(c->device));
+	for (auto &s : c->slot) {
+		if (s.stream) HIPCHK(hipStreamSynchronize(s.stream));
+		s.busy = false;
+	}
+	HIPCHK(hipStreamSynchronize(c->rstream));
+	if (t) {
+		memset(t, 0, sizeof *t);
+		if (c->reduced) {
+			t->total_kmers = c->red_totals[0];
+			t->total_hits = c->red_totals[1];
+			t->total_bases = c->red_totals[2];
+			t->reads_consumed = c->red_totals[3];
+		} else {
+			uint64_t dv[2];
+			int rc = read_device_totals(c, dv);
+			if (rc) return rc;
+			t->total_kmers = dv[0];
+			t->total_hits = dv[1];
+			t->total_bases = c->total_bases;
+			t->reads_consumed = c->reads_consumed;
+		}
+		t->early_stop = c->early_stop ? 1 : 0;
+	}
+	return NTSM_OK;
+}
+
+int ntsm_counts_device(ntsm_ctx *c, void **d_vec, uint64_t *n_words)
+{
+	if (!c) return NTSM_ERR_ARG;
+	ntsm_totals t;
+	int rc = ntsm_sync(c, &t);
+	if (rc) return rc;
+	if (!c->reduced) {
+		if (c->n_kmers) {
+			hipLaunchKernelGGL(ntsm_gather_kernel, dim3(1024), dim3(256), 0, c->rstream, c->d_slot_counts, c->d_slot_of, c->n_kmers, c->d_vec);
+			HIPCHK(hipGetLastError());
+		}
+		const uint64_t tail[4] = { t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed };
+		HIPCHK(hipMemcpyAsync(c->d_vec + c->n_kmers, tail, sizeof tail, hipMemcpyHostToDevice, c->rstream));
+		HIPCHK(hipStreamSynchronize(c->rstream));
+	}
+	if (d_vec) *d_vec = c->d_vec;
+	if (n_words) *n_words = (uint64_t) c->n_kmers + 4;
+	return NTSM_OK;
+}
+
+int ntsm_import_reduced(ntsm_ctx *c)
+{
+	if (!c) return NTSM_ERR_ARG;
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(c->red_totals, c->d_vec + c->n_kmers, sizeof c->red_totals, hipMemcpyDeviceToHost));
+	c->reduced = true;
+	return NTSM_OK;
+}
+
+int ntsm_counts(ntsm_ctx *c, uint64_t *out)
+{
+	if (!c || (!out && c->n_kmers)) return NTSM_ERR_ARG;
+	int rc = ntsm_counts_device(c, nullptr, nullptr);
+	if (rc) return rc;
+	if (c->n_kmers) HIPCHK(hipMemcpy(out, c->d_vec, (uint64_t) c->n_kmers * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	return NTSM_OK;
+}
+
+int ntsm_reset(ntsm_ctx *c)
+{
+	if (!c) return NTSM_ERR_ARG;
+	int rc = ntsm_sync(c, nullptr);
+	if (rc) return rc;
+	HIPCHK(hipMemset(c->d_slot_counts, 0, c->n_slots * sizeof(uint64_t)));
+	HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
+	c->total_bases = c->reads_consumed = 0;
+	c->early_stop = c->reduced = false;
+	return NTSM_OK;
+}
+
+int ntsm_set_timing(ntsm_ctx *c, int on)
+{
+	if (!c) return NTSM_ERR_ARG;
+	int rc = ntsm_sync(c, nullptr);
+	if (rc) return rc;
+	memset(c->ev_used, 0, sizeof c->ev_used);
+	c->ev_next = 0;
+	c->t_launches = 0;
+	c->t_ms = 0;
+	c->timing = on != 0;
+	return NTSM_OK;
+}
+
+int ntsm_get_timing(ntsm_ctx *c, uint64_t *n_launches, double *total_ms)
+{
+	if (!c) return NTSM_ERR_ARG;
+	int rc = ntsm_sync(c, nullptr);
+	if (rc) return rc;
+	for (int i = 0; i < kTimingPool; ++i)
+		if (c->ev_used[i]) {
+			float ms = 0;
+			HIPCHK(hipEventElapsedTime(&ms, c->ev_a[i], c->ev_b[i]));
+			c->t_ms += ms;
+			c->ev_used[i] = false;
+		}
+	if (n_launches) *n_launches = c->t_launches;
+	if (total_ms) *total_ms = c->t_ms;
+	return NTSM_OK;
+}
+
+int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
+{
+	if (!c) return NTSM_ERR_ARG;
+	int rc = ntsm_sync(c, nullptr);
+	if (rc) return rc;
+	c->grid_blocks = grid_blocks;
+	if (filter_log2_bits > 0 && (uint32_t) filter_log2_bits != c->filter_log2) {
+		/* counts are slot-indexed: keep them across the rebuild only if the table is untouched */
+		std::vector<uint64_t> saved(c->n_slots);
+		HIPCHK(hipMemcpy(saved.data(), c->d_slot_counts, c->n_slots * sizeof(uint64_t), hipMemcpyDeviceToHost));
+		const uint64_t old_slots = c->n_slots;
+		const std::vector<uint32_t> old_slot_of = c->slot_of;
+		rc = build_tables(c, filter_log2_bits);
+		if (rc) return rc;
+		if (c->n_slots == old_slots && c->slot_of == old_slot_of)
+			HIPCHK(hipMemcpy(c->d_slot_counts, saved.data(), c->n_slots * sizeof(uint64_t), hipMemcpyHostToDevice));
+	}
+	return NTSM_OK;
+}
+
+void *ntsm_stream(ntsm_ctx *c) { return c ? (void *) c->rstream : nullptr; }
+
+/* One process driving n GPUs: RCCL SUM of every context's dense count vector + totals over xGMI.
+ * SUM (not MAX): the per-site maxima are taken on the host from the summed per-k-mer counts,
+ * which is what a single reference run computes (src/FingerPrint.hpp:281-294). */
+int ntsm_allreduce(ntsm_ctx *const *ctxs, int n)
+{
+	if (!ctxs || n < 1) return NTSM_ERR_ARG;
+	for (int i = 0; i < n; ++i) {
+		if (!ctxs[i] || ctxs[i]->n_kmers != ctxs[0]->n_kmers) return NTSM_ERR_ARG;
+		int rc = ntsm_counts_device(ctxs[i], nullptr, nullptr);
+		if (rc) return rc;
+	}
+	if (n > 1) {
+		std::vector<int> devs(n);
+		std::vector<ncclComm_t> comms(n);
+		for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+		if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) return NTSM_ERR_RCCL;
+		bool ok = ncclGroupStart() == ncclSuccess;
+		for (int i = 0; i < n && ok; ++i) {
+			ok = hipSetDevice(devs[i]) == hipSuccess &&
+				ncclAllReduce(ctxs[i]->d_vec, ctxs[i]->d_vec, (size_t) ctxs[i]->n_kmers + 4, ncclUint64, ncclSum,
+						comms[i], ctxs[i]->rstream) == ncclSuccess;
+		}
+		ok = (ncclGroupEnd() == ncclSuccess) && ok;
+		for (int i = 0; i < n; ++i) {
+			(void) hipSetDevice(devs[i]);
+			(void) hipStreamSynchronize(ctxs[i]->rstream);
+			ncclCommDestroy(comms[i]);
+		}
+		if (!ok) return NTSM_ERR_RCCL;
+	}
+	for (int i = 0; i < n; ++i) {
+		int rc = ntsm_import_reduced(ctxs[i]);
+		if (rc) return rc;
+	}
+	return NTSM_OK;
+}
+
+} // extern "C"

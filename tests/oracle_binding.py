@@ -1,0 +1,116 @@
+"""ctypes binding of the CPU oracle (oracle/libntsm_oracle.so) -- test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ROOT, "oracle", "libntsm_oracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libntsm_oracle.so", "ntsm_oracle"], check=True)
+        L = C.CDLL(path)
+        u64p = C.POINTER(C.c_uint64)
+        L.ntsm_oracle_hash64.restype = C.c_uint64
+        L.ntsm_oracle_hash64.argtypes = [C.c_uint64, C.c_uint64]
+        L.ntsm_oracle_mask.restype = C.c_uint64
+        L.ntsm_oracle_mask.argtypes = [C.c_uint]
+        L.ntsm_oracle_nt4.restype = C.c_int
+        L.ntsm_oracle_nt4.argtypes = [C.c_ubyte]
+        L.ntsm_oracle_kmers.restype = C.c_uint64
+        L.ntsm_oracle_kmers.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, u64p, u64p, u64p, C.c_uint64]
+        L.ntsm_oracle_reader_open.restype = C.c_void_p
+        L.ntsm_oracle_reader_open.argtypes = [C.c_char_p]
+        L.ntsm_oracle_reader_next.restype = C.c_int64
+        L.ntsm_oracle_reader_next.argtypes = [C.c_void_p]
+        L.ntsm_oracle_reader_seq.restype = C.c_void_p
+        L.ntsm_oracle_reader_seq.argtypes = [C.c_void_p]
+        L.ntsm_oracle_reader_name.restype = C.c_char_p
+        L.ntsm_oracle_reader_name.argtypes = [C.c_void_p]
+        L.ntsm_oracle_reader_close.argtypes = [C.c_void_p]
+        L.ntsm_oracle_fp_create.restype = C.c_void_p
+        L.ntsm_oracle_fp_create.argtypes = [C.c_char_p, C.c_uint, C.c_double, C.c_int, C.c_void_p]
+        L.ntsm_oracle_fp_destroy.argtypes = [C.c_void_p]
+        L.ntsm_oracle_fp_insert_count.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        L.ntsm_oracle_fp_process_read.restype = C.c_int
+        L.ntsm_oracle_fp_process_read.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        for f in ("total_kmers", "total_hits", "total_bases", "max_hits", "reads_processed", "n_distinct", "n_sites"):
+            fn = getattr(L, "ntsm_oracle_fp_" + f)
+            fn.restype = C.c_uint64
+            fn.argtypes = [C.c_void_p]
+        L.ntsm_oracle_fp_early_term.restype = C.c_int
+        L.ntsm_oracle_fp_early_term.argtypes = [C.c_void_p]
+        L.ntsm_oracle_fp_kmers.restype = C.c_uint64
+        L.ntsm_oracle_fp_kmers.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def read_records(path):
+    """All (name, sequence-bytes) the oracle's reader yields + its terminating code."""
+    L = lib()
+    r = L.ntsm_oracle_reader_open(os.fsencode(path))
+    assert r, path
+    out = []
+    while True:
+        n = L.ntsm_oracle_reader_next(r)
+        if n < 0:
+            break
+        out.append((L.ntsm_oracle_reader_name(r), C.string_at(L.ntsm_oracle_reader_seq(r), n)))
+    L.ntsm_oracle_reader_close(r)
+    return out, int(n)
+
+
+class OracleFP:
+    """ntsm_oracle_fp wrapper: the reference FingerPrint on the CPU."""
+    DBL_MAX = 1.7976931348623157e308
+
+    def __init__(self, sites_path, k=19, cov=DBL_MAX, dupes=False):
+        self.L = lib()
+        self.h = self.L.ntsm_oracle_fp_create(os.fsencode(sites_path), k, cov, int(dupes), None)
+        assert self.h, sites_path
+
+    def process(self, seq):
+        """processSingleRead; returns True once the -m threshold tripped."""
+        return bool(self.L.ntsm_oracle_fp_process_read(self.h, seq, len(seq)))
+
+    def process_flat(self, bases, read_end):
+        """Feed a flat stream read by read, stopping like computeCounts does."""
+        buf = bases.tobytes()
+        start = 0
+        for e in read_end.tolist():
+            if self.early_term:
+                break
+            self.process(buf[start:e])
+            start = e + 1
+
+    def __getattr__(self, name):
+        if name in ("total_kmers", "total_hits", "total_bases", "max_hits", "reads_processed", "n_distinct", "n_sites"):
+            return int(getattr(self.L, "ntsm_oracle_fp_" + name)(self.h))
+        if name == "early_term":
+            return bool(self.L.ntsm_oracle_fp_early_term(self.h))
+        raise AttributeError(name)
+
+    def kmers(self):
+        n = self.L.ntsm_oracle_fp_kmers(self.h, None, None, None, 0)
+        canon = np.zeros(n, np.uint64); hv = np.zeros(n, np.uint64); cnt = np.zeros(n, np.uint64)
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint64))
+        self.L.ntsm_oracle_fp_kmers(self.h, p(canon), p(hv), p(cnt), n)
+        return canon, hv, cnt
+
+    def close(self):
+        if self.h:
+            self.L.ntsm_oracle_fp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

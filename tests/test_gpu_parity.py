@@ -1,0 +1,271 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, must give
+the oracle's per-k-mer counts and totals bit for bit, and the CLI must print the reference's bytes."""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_binding import OracleFP
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+GOLD = json.load(open(os.path.join(G, "cases.json")))
+CASES = GOLD["cases"]
+OK_CASES = [c for c in CASES if c["rc"] == 0]
+
+
+@pytest.fixture(scope="module")
+def nt(built):
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import ntsm_amd
+    return ntsm_amd
+
+
+def _k(case):
+    return int(case["args"][case["args"].index("-k") + 1]) if "-k" in case["args"] else 19
+
+
+def _cov(case):
+    return float(case["args"][case["args"].index("-m") + 1]) if "-m" in case["args"] else OracleFP.DBL_MAX
+
+
+def _sites(case):
+    return os.path.join(G, "inputs", case["args"][case["args"].index("-s") + 1])
+
+
+def _summary(err):
+    keep = (b"Total ", b"Distinct ", b"Sites Covered", b"Warning: site coverage", b"Reached desired", b"Warning: ")
+    return [l for l in err.split(b"\n") if l.startswith(keep)]
+
+
+@pytest.mark.parametrize("case", OK_CASES, ids=[c["name"] for c in OK_CASES])
+def test_c_abi_matches_golden_and_oracle(nt, case):
+    """ntsm_create + ntsm_submit per file + ntsm_counts == recorded reference stdout == oracle state."""
+    k, cov, dupes = _k(case), _cov(case), "-d" in case["args"]
+    sites = nt.Sites(_sites(case), k=k, allow_dupes=dupes)
+    fp = OracleFP(_sites(case), k=k, cov=cov, dupes=dupes)
+    ctx = nt.Context(sites.keys, k=k, max_hits=nt.max_hits_for(len(sites.keys), cov))
+    for f in case["files"]:
+        bases, ends, _ = nt.flatten_file(os.path.join(G, "inputs", f))
+        ctx.submit(bases, ends)
+        fp.process_flat(bases, ends)
+    t = ctx.sync()
+    counts = ctx.counts()
+    _, _, ocnt = fp.kmers()
+    assert np.array_equal(counts, ocnt)
+    assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases)
+    assert bool(t.early_stop) == fp.early_term
+    assert t.reads_consumed == fp.reads_processed
+    rc, text = sites.format_counts(counts, t.total_kmers)
+    assert rc == 0 and text == open(os.path.join(G, "expected", case["stdout"]), "rb").read()
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_cli_matches_reference_bytes(nt, case):
+    """build/ntsmCount: stdout byte-identical, summary lines identical, abort where the reference aborts."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    p = subprocess.run([exe] + case["args"] + case["files"], cwd=os.path.join(G, "inputs"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if case["rc"] != 0:
+        assert p.returncode == case["rc"], p.stderr[-500:]          # -6: SIGABRT like the reference
+        return
+    assert p.returncode == 0, p.stderr[-500:]
+    assert p.stdout == open(os.path.join(G, "expected", case["stdout"]), "rb").read()
+    assert _summary(p.stderr) == _summary(open(os.path.join(G, "expected", case["stderr"]), "rb").read())
+
+
+def test_cli_small_batches_and_summary_file(nt, tmp_path):
+    """Batch boundaries must not matter: tiny staging slots (env override) give identical bytes; -o is written."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    case = next(c for c in CASES if c["name"] == "tiny_multifile")
+    env = dict(os.environ, NTSM_BATCH_BYTES="8192")
+    out = str(tmp_path / "summary.txt")
+    p = subprocess.run([exe] + case["args"] + ["-o", out] + case["files"], cwd=os.path.join(G, "inputs"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert p.stdout == open(os.path.join(G, "expected", case["stdout"]), "rb").read()
+    exp = [l for l in open(os.path.join(G, "expected", case["stderr"]), "rb").read().split(b"\n")
+           if l.startswith((b"Total ", b"Distinct ", b"Sites Covered"))]
+    assert open(out, "rb").read().split(b"\n")[:6] == exp
+    # -m with tiny batches: the crossing read is found inside whichever batch it falls in
+    for name in ("m_1_midfile", "m_file_boundary_stop", "m_file_boundary_continue", "m_long"):
+        c = next(x for x in CASES if x["name"] == name)
+        p = subprocess.run([exe] + c["args"] + c["files"], cwd=os.path.join(G, "inputs"), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=dict(os.environ, NTSM_BATCH_BYTES="20000"))
+        assert p.returncode == 0, p.stderr[-500:]
+        assert p.stdout == open(os.path.join(G, "expected", c["stdout"]), "rb").read(), name
+        assert _summary(p.stderr) == _summary(open(os.path.join(G, "expected", c["stderr"]), "rb").read()), name
+
+
+def test_cli_config0_sha256(nt, tmp_path):
+    """BASELINE.json configs[0]: 96287 sites x 100k reads through the CLI == reference counts.txt."""
+    c0 = GOLD["config0"]
+    s = nt.SynthShort(sites_seed=c0["sites"]["seed"], n_sites=c0["sites"]["n_sites"], read_seed=c0["reads"]["seed"],
+                      sites_path=str(tmp_path / "sites.fa"))
+    s.write_fastq(str(tmp_path / "reads.fq"), 0, c0["reads"]["n_reads"])
+    assert hashlib.sha256(open(tmp_path / "sites.fa", "rb").read()).hexdigest() == c0["sites"]["sha256"]
+    assert hashlib.sha256(open(tmp_path / "reads.fq", "rb").read()).hexdigest() == c0["reads"]["sha256"]
+    p = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", str(tmp_path / "sites.fa"), str(tmp_path / "reads.fq")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert hashlib.sha256(p.stdout).hexdigest() == c0["counts_sha256"]
+    assert p.stdout == gzip.open(os.path.join(G, "expected", c0["counts_gz"])).read()
+    assert _summary(p.stderr) == _summary(open(os.path.join(G, "expected", c0["stderr"]), "rb").read())
+
+
+@pytest.fixture(scope="module")
+def n10(nt, tmp_path_factory):
+    """hs_n10_like sites (96287 sites, 1.54 M k-mers) + oracle + context, shared by the big tests."""
+    d = tmp_path_factory.mktemp("n10")
+    s = nt.SynthShort(sites_seed=20241218, n_sites=96287, read_seed=99, sites_path=str(d / "sites.fa"))
+    sites = nt.Sites(str(d / "sites.fa"))
+    return s, sites, str(d / "sites.fa")
+
+
+def test_random_reads_vs_oracle_n10(nt, n10):
+    """300k seeded reads against the full site set: counts and totals equal the oracle's."""
+    s, sites, path = n10
+    n = 300_000
+    bases = s.host_bytes(0, n)
+    ends = s.read_end(n)
+    fp = OracleFP(path)
+    fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)   # one long "read": terminators reset windows
+    ctx = nt.Context(sites.keys)
+    half = (n // 2) * s.stride
+    ctx.submit(bases[:half], ends[:n // 2])                                # two batches -> both staging slots
+    ctx.submit(bases[half:], ends[n // 2:] - np.uint64(half))
+    t = ctx.sync()
+    _, _, ocnt = fp.kmers()
+    assert np.array_equal(ctx.counts(), ocnt)
+    assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
+    assert t.total_bases == n * s.read_len and t.reads_consumed == n
+    assert t.total_hits > 1000
+    ctx.close()
+
+
+def test_resident_path_properties_at_scale(nt, n10):
+    """2e7 reads generated on the device (3 GB): device fill == host fill on a sample; counting twice
+    doubles every count (linearity); sign = -1 takes a batch out again exactly; the reverse-complemented
+    stream gives identical counts (canonical k-mers); hash64-keyed creation equals canonical-keyed."""
+    import torch
+    s, sites, path = n10
+    n = 20_000_000
+    dev = torch.device("cuda:0")
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d_bases = torch.empty(n * s.stride, dtype=torch.uint8, device=dev)
+    s.device_fill(d_win.data_ptr(), 0, n, d_bases.data_ptr())
+    torch.cuda.synchronize()
+    sample = d_bases[1000 * s.stride:1500 * s.stride].cpu().numpy()
+    assert np.array_equal(sample, s.host_bytes(1000, 500))
+    tail = d_bases[(n - 100) * s.stride:].cpu().numpy()
+    assert np.array_equal(tail, s.host_bytes(n - 100, 100))
+
+    ctx = nt.Context(sites.keys)
+    ctx.count_resident(d_bases.data_ptr(), d_bases.numel(), 0, n)
+    t1, c1 = ctx.sync(), ctx.counts()
+    assert t1.total_bases == n * s.read_len
+    # oracle on a prefix, GPU on the same prefix
+    m = 200_000
+    fp = OracleFP(path)
+    pre = s.host_bytes(0, m)
+    fp.L.ntsm_oracle_fp_insert_count(fp.h, pre.tobytes(), pre.size)
+    ctx2 = nt.Context(np.array([nt.hash64(int(x), 19) for x in sites.keys[:5000]], dtype=np.uint64), key_kind=1)
+    ctx2.count_resident(d_bases.data_ptr(), m * s.stride, 0, m)
+    assert np.array_equal(ctx2.counts(), fp.kmers()[2][:5000])
+    ctx2.close()
+    # linearity
+    ctx.count_resident(d_bases.data_ptr(), d_bases.numel(), 0, n)
+    t2, c2 = ctx.sync(), ctx.counts()
+    assert np.array_equal(c2, 2 * c1) and t2.total_kmers == 2 * t1.total_kmers and t2.total_hits == 2 * t1.total_hits
+    # exact removal
+    ctx.count_resident(d_bases.data_ptr(), d_bases.numel(), 0, n, sign=-1)
+    t3, c3 = ctx.sync(), ctx.counts()
+    assert np.array_equal(c3, c1) and (t3.total_kmers, t3.total_hits, t3.total_bases) == (t1.total_kmers, t1.total_hits, t1.total_bases)
+    # sub-range + remainder == whole (split at a read boundary that is not 16-byte aligned)
+    ctx.reset()
+    cut = 7_000_001 * s.stride
+    ctx.count_resident(d_bases.data_ptr(), cut, 0, 7_000_001)
+    rest = d_bases[cut:].clone()                    # re-based copy keeps 16-byte alignment of the pointer
+    ctx.count_resident(rest.data_ptr(), rest.numel(), 0, n - 7_000_001)
+    assert np.array_equal(ctx.counts(), c1) and ctx.sync().total_kmers == t1.total_kmers
+    # reverse complement of the whole stream: same canonical k-mers, same counts
+    lut = torch.arange(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        lut[a] = b
+    rc = lut[d_bases.flip(0).long()] if n <= 1_000_000 else None
+    if rc is None:
+        part = d_bases[:3_000_000 * s.stride]
+        rc = lut[part.flip(0).long()].contiguous()
+        ctx.reset(); ctx.count_resident(part.data_ptr(), part.numel(), 0, 3_000_000); fwd = ctx.counts(); tf = ctx.sync()
+        ctx.reset(); ctx.count_resident(rc.data_ptr(), rc.numel(), 0, 3_000_000); rev = ctx.counts(); tr = ctx.sync()
+        assert np.array_equal(fwd, rev) and tf.total_kmers == tr.total_kmers and tf.total_hits == tr.total_hits
+    ctx.close()
+
+
+def test_other_k_random_vs_oracle(nt, tmp_path):
+    """k in {1, 5, 16, 17, 27, 31, 32} (register-width boundaries, the degenerate k = 32) on random reads with N."""
+    rng = np.random.default_rng(5)
+    for k in (1, 5, 16, 17, 27, 31, 32):
+        path = str(tmp_path / ("s%d.fa" % k))
+        seqs = ["".join(rng.choice(list("ACGT"), size=60)) for _ in range(40)]
+        with open(path, "w") as f:
+            for i, sq in enumerate(seqs):
+                f.write(">s%d\n%s\n" % (i // 2, sq if k > 8 else sq[:k]))
+        dupes = True
+        sites = nt.Sites(path, k=k, allow_dupes=dupes)
+        fp = OracleFP(path, k=k, dupes=dupes)
+        reads = []
+        for i in range(400):
+            src = seqs[rng.integers(len(seqs))]
+            a = rng.integers(0, 30)
+            r = list(src[a:a + rng.integers(k, 60)] + "".join(rng.choice(list("ACGTN"), size=rng.integers(0, 50), p=[.24, .24, .24, .24, .04])))
+            reads.append("".join(r).encode())
+        bases, ends = nt.capi.flatten_reads(reads)
+        ctx = nt.Context(sites.keys, k=k)
+        ctx.submit(bases, ends)
+        fp.process_flat(bases, ends)
+        t = ctx.sync()
+        assert np.array_equal(ctx.counts(), fp.kmers()[2]), k
+        assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases), k
+        ctx.close()
+
+
+def test_early_stop_resident_and_batched(nt, n10):
+    """-m semantics on the GPU: stop after the first read that lifts total hits strictly above the
+    threshold, wherever the batch boundaries are; reads after it contribute nothing."""
+    s, sites, path = n10
+    n = 120_000
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    full = OracleFP(path)
+    full.L.ntsm_oracle_fp_insert_count(full.h, bases.tobytes(), bases.size)
+    for frac in (0.013, 0.5):
+        thr = int(full.total_hits * frac)
+        cov = 2.0 * (thr + 0.5) / len(sites.keys)
+        fp = OracleFP(path, cov=cov)
+        assert fp.max_hits == thr
+        fp.process_flat(bases, ends)
+        assert fp.early_term
+        for n_batches in (1, 7):
+            ctx = nt.Context(sites.keys, max_hits=thr)
+            per = -(-n // n_batches)
+            for b in range(n_batches):
+                lo, hi = b * per, min(n, (b + 1) * per)
+                ctx.submit(bases[lo * s.stride:hi * s.stride], ends[lo:hi] - np.uint64(lo * s.stride))
+            t = ctx.sync()
+            assert t.early_stop == 1 and t.reads_consumed == fp.reads_processed
+            assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases)
+            assert np.array_equal(ctx.counts(), fp.kmers()[2])
+            ctx.close()
+
+
+def test_duplicate_keys_rejected(nt):
+    with pytest.raises(nt.NtsmError):
+        nt.Context(np.array([5, 9, 5], dtype=np.uint64), k=19)
