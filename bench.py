@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter-log2", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (fast path for k=19), 1 generic")
     args = ap.parse_args()
 
     import torch
@@ -81,6 +82,8 @@ def main():
     ctx = ntsm_amd.Context(sites.keys, k=K, device=local)
     if args.filter_log2 or args.grid:
         ctx.set_tuning(args.filter_log2, args.grid)
+    if args.kernel:
+        ctx.set_kernel(args.kernel)
 
     # workload resident in HBM: this rank's reads [rank*n, (rank+1)*n) of the global synthetic stream
     d_win = torch.from_numpy(synth.windows).to(dev)

@@ -117,6 +117,9 @@ int ntsm_set_timing(ntsm_ctx *ctx, int on);
 int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
 /* Tuning knobs (0 = automatic): log2 of filter bits, grid blocks.  For profiling experiments. */
 int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
+/* Kernel choice: 0 = automatic (minimizer-blocked fast path when k == 19, generic otherwise),
+ * 1 = always the generic kernel.  Both give identical results; for A/B measurements. */
+int ntsm_set_kernel(ntsm_ctx *ctx, int variant);
 /* The HIP stream (hipStream_t) ntsm_count_resident launches on. */
 void *ntsm_stream(ntsm_ctx *ctx);
 

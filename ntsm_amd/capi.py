@@ -69,6 +69,7 @@ _sig(H, "ntsm_reset", C.c_int, [C.c_void_p])
 _sig(H, "ntsm_set_timing", C.c_int, [C.c_void_p, C.c_int])
 _sig(H, "ntsm_get_timing", C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_double)])
 _sig(H, "ntsm_set_tuning", C.c_int, [C.c_void_p, C.c_int, C.c_int])
+_sig(H, "ntsm_set_kernel", C.c_int, [C.c_void_p, C.c_int])
 _sig(H, "ntsm_stream", C.c_void_p, [C.c_void_p])
 _sig(H, "ntsm_hash64", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_hash64_inv", C.c_uint64, [C.c_uint64, C.c_int])
@@ -243,6 +244,9 @@ class Context:
 
     def set_tuning(self, filter_log2_bits=0, grid_blocks=0):
         _chk(H.ntsm_set_tuning(self._h, filter_log2_bits, grid_blocks), "ntsm_set_tuning")
+
+    def set_kernel(self, variant):
+        _chk(H.ntsm_set_kernel(self._h, int(variant)), "ntsm_set_kernel")
 
     @property
     def stream(self):

@@ -34,6 +34,40 @@ NTSM_DHD uint32_t ntsm_fold(uint64_t x)
 NTSM_DHD uint32_t ntsm_h1(uint32_t folded) { return folded * 0x9E3779B1u; }
 NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC2B2AE35u + 0x27D4EB2Fu; }
 
+/* ---- k = 19 fast path: minimizer-blocked filter -----------------------------------------------
+ * Consecutive k-mers of a read share their minimizer (smallest hashed canonical 12-mer inside the
+ * 19-mer, 8 candidates) for 4.5 positions on average, so the filter is addressed by the MINIMIZER
+ * (one 64-bit block per minimizer hash) and a lane re-reads L2 only when its minimizer changes:
+ * ~0.22 L2 requests per k-mer instead of 1.  Inside the block every site k-mer sets two bits chosen
+ * by a strand-symmetric hash of (fw, rc).  All functions below are shared by the host builder and
+ * the kernel so that both sides agree bit for bit. */
+#define NTSM_FAST_K 19
+#define NTSM_FAST_M 12
+#define NTSM_FAST_W (NTSM_FAST_K - NTSM_FAST_M + 1)
+
+/* order hash of a canonical 12-mer (24 bits): injective scramble, compared as an integer */
+NTSM_DHD uint32_t ntsm_mmer_hash(uint32_t cm)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __umul24(cm, 0x9E3779u);
+#else
+	return (uint32_t) ((uint64_t) cm * 0x9E3779u);
+#endif
+}
+/* filter block of a minimizer value */
+NTSM_DHD uint32_t ntsm_block_of(uint32_t mz, uint32_t blk_shift) { return (mz * 0x9E3779B1u) >> blk_shift; }
+/* Two filter bits per site k-mer, one in each 32-bit half of the block: bit (h & 31) of the low
+ * word and bit ((h >> 5) & 31) of the high word.  fh / rh are the top 32 bits of the 38-bit forward
+ * and reverse-complement codes (code >> 6): together they cover all 19 bases, and the sum is
+ * symmetric in the two strands, so the hot loop needs no canonical min. */
+NTSM_DHD uint32_t ntsm_kmer_bits(uint32_t fh, uint32_t rh)
+{
+	const uint32_t u = fh + rh;
+	return u ^ (u >> 15);
+}
+/* a minimizer value that no 12-mer produces (0x9E3779 * 2^24 mod 2^32): "no block cached yet" */
+#define NTSM_NO_MINIMIZER 0x79000000u
+
 struct NtsmCountParams {
 	const uint8_t *base;               /* 16-byte aligned start of the flat stream */
 	long long lo, hi;                  /* count windows ending at byte offsets in [lo, hi) */
@@ -52,6 +86,9 @@ struct NtsmCountParams {
 	uint32_t kmask;                    /* low k bits set: window validity */
 	uint32_t fshift, bshift;           /* bit index = h1 >> fshift ; bucket = h >> bshift */
 	const uint8_t *lut;                /* 256-byte base table, vendor/KseqHashIterator.hpp:114-127 */
+	const uint2 *lut64;                /* fast path: per byte { code << 26, (3 - code) | invalid << 31 } */
+	const unsigned long long *blocks;  /* k = 19 fast path: minimizer-addressed 64-bit filter blocks */
+	uint32_t blk_shift;                /* block index = (mz * C) >> blk_shift */
 };
 
 #endif

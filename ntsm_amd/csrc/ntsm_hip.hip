@@ -190,6 +190,216 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 	}
 }
 
+/* --------------------------------------------------------------------------------------------
+ * k = 19 fast path.  Same tiling as the generic kernel; per position a lane
+ *   1. rolls fw / rc (two 32-bit words each) and the canonical 12-mer order hash,
+ *   2. keeps the sliding minimum over the 8 12-mers of the 19-mer (block-decomposed: prefix minima
+ *      of the current 8-block against suffix minima of the previous one),
+ *   3. re-reads its 64-bit filter block from L2 only when the minimizer changed,
+ *   4. tests two block bits chosen by a strand-symmetric hash; positives are queued by tile offset
+ *      in a wave-private LDS queue.
+ * Whenever 64 positives are queued the wave drains them with every lane busy: the k-mer is rebuilt
+ * from the tile bytes still in LDS, its canonical code looked up in the cuckoo table (bucket 2
+ * only if bucket 1 is full), and the slot counter bumped with one 64-bit atomic.
+ * ------------------------------------------------------------------------------------------ */
+#ifndef NTSM_FAST_WAVES
+#define NTSM_FAST_WAVES 4                              /* waves per SIMD the register budget is held to */
+#endif
+constexpr int kFastC = 128;
+constexpr int kQueueCap = 64 + 8 * 64;                 /* < 64 left over + one 8-position burst */
+
+/* LDS image of a tile: row r (128 B) = stream bytes of thread r-1 (row 0 = the 32 bytes in front of
+ * the tile, in its last two slots).  16-byte slot s of row r sits at physical slot s ^ ((r >> 1) & 7):
+ * the per-thread ds_read_b128/b64 of "slot s of my row" is then bank-conflict free without padding. */
+__device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
+{
+	return row * kFastC + ((((byte_in_row >> 4) ^ (row >> 1)) & 7) << 4) + (byte_in_row & 15);
+}
+
+template <bool PER_READ>
+__global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kernel(const NtsmCountParams p)
+{
+	constexpr int C = kFastC, VPT = C / 16;
+	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * C];
+	__shared__ uint2 lut64[256];
+	__shared__ uint16_t queue_all[kThreads / 64][kQueueCap];
+	const int t = threadIdx.x;
+	const int lane = t & 63;
+	uint16_t *queue = queue_all[t >> 6];
+	lut64[t] = p.lut64[t];
+	const uint32_t bshift = p.bshift, blk_shift = p.blk_shift;
+	uint32_t nk = 0, nh = 0;
+
+	for (unsigned long long ti = blockIdx.x; ti < p.n_tiles; ti += gridDim.x) {
+		const long long ts = p.t0 + (long long) (ti * (unsigned long long) (kThreads * C));
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < VPT; ++q) {
+			const int v = t + kThreads * q;
+			const uint4 r = ntsm_load_vec(p, ts + 16ll * v);
+			*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr(1 + v / VPT, (v % VPT) * 16)) = r;
+		}
+		if (t < 2) {
+			const uint4 r = ntsm_load_vec(p, ts - 32 + 16 * t);
+			*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr(0, C - 32 + 16 * t)) = r;
+		}
+		__syncthreads();
+
+		/* 38-bit forward / reverse-complement codes kept LEFT-aligned in 64 bits (code << 26):
+		 * the forward code drops its oldest base off the top by itself, the reverse code lets old
+		 * bases fall below bit 26 where nothing reads them -- 2 ops each per base, no masks. */
+		uint32_t FH = 0, FL = 0, RH = 0, RL = 0, inv = 0xFFFFFFFFu;
+		uint32_t sprev[8];                                  /* suffix minima of the previous 8-block, [1..7] used */
+		uint32_t qn = 0;                                    /* wave-uniform queue fill */
+#define NTSM_ROLL19(byte_)                                                                \
+		{                                                                                 \
+			const uint2 e_ = lut64[(byte_)];                                              \
+			FH = __builtin_amdgcn_alignbit(FH, FL, 30);                                   \
+			FL = (FL << 2) | e_.x;                                                        \
+			RL = __builtin_amdgcn_alignbit(RH, RL, 2);                                    \
+			RH = __builtin_amdgcn_alignbit(e_.y, RH, 2);                                  \
+			inv = __builtin_amdgcn_alignbit(inv, e_.y, 31);                               \
+		}
+#define NTSM_ROLL19E(e_)                                                                  \
+		{                                                                                 \
+			FH = __builtin_amdgcn_alignbit(FH, FL, 30);                                   \
+			FL = (FL << 2) | (e_).x;                                                      \
+			RL = __builtin_amdgcn_alignbit(RH, RL, 2);                                    \
+			RH = __builtin_amdgcn_alignbit((e_).y, RH, 2);                                \
+			inv = __builtin_amdgcn_alignbit(inv, (e_).y, 31);                             \
+		}
+#define NTSM_MMER_G() ntsm_mmer_hash(min(__builtin_amdgcn_alignbit(FH, FL, 26) & 0xFFFFFFu, RH >> 8))
+		{   /* warm-up: the 18 bytes in front of the chunk; 12-mer hashes of positions -7..-1 */
+			const uint4 v0 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 32));
+			const uint4 v1 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 16));
+			const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+			uint32_t gw[8];
+#pragma unroll
+			for (int i = 14; i < 32; ++i) {
+				NTSM_ROLL19((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu)
+				if (i >= 25) gw[i - 24] = NTSM_MMER_G();     /* i = 25..31 -> block index 1..7 */
+			}
+			sprev[7] = gw[7];
+#pragma unroll
+			for (int i = 6; i >= 1; --i) sprev[i] = min(gw[i], sprev[i + 1]);
+		}
+		uint32_t cur_mz = NTSM_NO_MINIMIZER, cur_lo = 0, cur_hi = 0;
+
+		/* drain: look up queued positives, 64 at a time (or the remainder when `all`) */
+		auto drain = [&](bool all) {
+			while (qn >= 64 || (all && qn > 0)) {
+				const uint32_t n = qn < 64 ? qn : 64;
+				qn -= n;
+				if ((uint32_t) lane < n) {
+					const int off = queue[qn + lane];            /* tile offset of the window's last base */
+					uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+					uint32_t cc[19];
+#pragma unroll
+					for (int j = 0; j < 19; ++j) {                /* 19 independent LDS reads, then 19 table reads */
+						const int x = off - 18 + j + C;           /* +C: row 0 is the halo row */
+						cc[j] = tile[ntsm_tile_addr(x >> 7, x & (C - 1))];
+					}
+#pragma unroll
+					for (int j = 0; j < 19; ++j) cc[j] = lut64[cc[j]].y & 3u;   /* 3 - code */
+#pragma unroll
+					for (int j = 0; j < 19; ++j) {
+						const uint32_t c3_ = cc[j], c_ = 3u - c3_;
+						a_hi = ((a_hi << 2) | (a_lo >> 30)) & 0x3Fu;
+						a_lo = (a_lo << 2) | c_;
+						b_lo = (b_lo >> 2) | (b_hi << 30);
+						b_hi = (b_hi >> 2) | (c3_ << 4);
+					}
+					const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
+					const uint32_t klo = lt ? a_lo : b_lo, khi = lt ? a_hi : b_hi;
+					const uint32_t fo = ntsm_fold(((unsigned long long) khi << 32) | klo);
+					const unsigned long long b1 = 2ull * (ntsm_h1(fo) >> bshift);
+					const uint4 ba = *reinterpret_cast<const uint4 *>(p.keys + b1);
+					long long slot = -1;
+					if (ba.x == klo && ba.y == khi) slot = (long long) b1;
+					else if (ba.z == klo && ba.w == khi) slot = (long long) b1 + 1;
+					else if ((ba.x & ba.y) != 0xFFFFFFFFu && (ba.z & ba.w) != 0xFFFFFFFFu) {
+						/* bucket 1 full and no match: the key can only be in bucket 2 */
+						const unsigned long long b2 = 2ull * (ntsm_h2(fo) >> bshift);
+						const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + b2);
+						if (bb.x == klo && bb.y == khi) slot = (long long) b2;
+						else if (bb.z == klo && bb.w == khi) slot = (long long) b2 + 1;
+					}
+					if (slot >= 0) {
+						__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						++nh;
+						if (PER_READ)
+							atomicAdd(p.read_hits + ntsm_read_of(p, (unsigned long long) (ts + off)), 1u);
+					}
+				}
+			}
+		};
+
+#pragma unroll 1
+		for (int b8 = 0; b8 < C / 8; ++b8) {                   /* 8 positions per step = one sliding-min block */
+			const uint2 v = *reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, b8 * 8));
+			const uint32_t w[2] = { v.x, v.y };
+			uint32_t mz[8], kb[8], gg[8], idx[8], pm = 0xFFFFFFFFu;
+			uint32_t okm = 0, needm = 0;                        /* per-lane bit j: window j valid / block j fetched */
+			/* phase A: roll, 12-mer hashes, sliding minimum, k-mer bit hash, block index */
+			uint2 e8[8];                                        /* the 8 table reads issue together, ahead of the dependent roll chain */
+#pragma unroll
+			for (int j = 0; j < 8; ++j) e8[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				NTSM_ROLL19E(e8[j])
+				gg[j] = NTSM_MMER_G();
+				pm = min(pm, gg[j]);
+				mz[j] = j < 7 ? min(sprev[j + 1], pm) : pm;
+				kb[j] = ntsm_kmer_bits(FH, RH);
+				const bool ok = (inv & 0x7FFFFu) == 0;
+				const bool nd = ok && mz[j] != cur_mz;
+				okm |= ok ? (1u << j) : 0u;
+				needm |= nd ? (1u << j) : 0u;
+				idx[j] = nd ? ntsm_block_of(mz[j], blk_shift) : 0u;   /* lanes that keep their block all read block 0 */
+				cur_mz = nd ? mz[j] : cur_mz;
+			}
+			sprev[7] = gg[7];
+#pragma unroll
+			for (int j = 6; j >= 1; --j) sprev[j] = min(gg[j], sprev[j + 1]);
+			nk += (uint32_t) __popc(okm);
+			/* phase B: eight unconditional 8-byte loads in flight together (one L2 request per changed minimizer) */
+			uint2 bl[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) bl[j] = *reinterpret_cast<const uint2 *>(p.blocks + idx[j]);
+			/* phase C: bit tests, queue the positives */
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const bool nd = (needm >> j) & 1u;
+				cur_lo = nd ? bl[j].x : cur_lo;
+				cur_hi = nd ? bl[j].y : cur_hi;
+				const bool pass = ((cur_lo >> (kb[j] & 31u)) & (cur_hi >> ((kb[j] >> 5) & 31u)) & (okm >> j) & 1u) != 0;
+				const unsigned long long m = __ballot(pass);
+				if (m) {
+					if (pass) {
+						const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+						queue[at] = (uint16_t) (t * C + b8 * 8 + j);
+					}
+					qn += (uint32_t) __popcll(m);
+				}
+			}
+			if (qn >= 64) drain(false);
+		}
+		drain(true);
+#undef NTSM_ROLL19
+#undef NTSM_ROLL19E
+#undef NTSM_MMER_G
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		nk += __shfl_down(nk, off, 64);
+		nh += __shfl_down(nh, off, 64);
+	}
+	if ((t & 63) == 0) {
+		if (nk) atomicAdd(p.totals + 0, p.sign * (unsigned long long) nk);
+		if (nh) atomicAdd(p.totals + 1, p.sign * (unsigned long long) nh);
+	}
+}
+
 /* dense[i] = slot_counts[slot_of[i]]; tail = totals */
 __global__ void ntsm_gather_kernel(const unsigned long long *slot_counts, const uint32_t *slot_of,
 		uint32_t n, unsigned long long *dense)
@@ -267,8 +477,12 @@ struct ntsm_ctx {
 	uint64_t *d_keys = nullptr;
 	unsigned long long *d_slot_counts = nullptr, *d_totals = nullptr, *d_vec = nullptr;
 	uint8_t *d_lut = nullptr;
+	uint2 *d_lut64 = nullptr;
 	uint32_t filter_log2 = 0, bucket_log2 = 0;
 	uint64_t n_slots = 0;
+	unsigned long long *d_blocks = nullptr;    /* k = 19 fast path: minimizer-addressed filter blocks */
+	uint32_t block_log2 = 0;                   /* log2(number of 64-bit blocks) */
+	int kernel_variant = 0;                    /* 0 auto (fast path when k == 19), 1 generic */
 	std::vector<uint64_t> canon;               /* host copy of the canonical keys */
 	std::vector<uint32_t> slot_of;
 	/* batching */
@@ -355,7 +569,37 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		const uint32_t bit = ntsm_h1(ntsm_fold(c->canon[i])) >> fshift;
 		filter[bit >> 5] |= 1u << (bit & 31);
 	}
+	/* k = 19: minimizer-addressed blocked filter (>= 16 bits per key: 4 MiB for the human set) */
+	std::vector<unsigned long long> blocks;
+	if (c->k == NTSM_FAST_K) {
+		uint32_t bits_log2 = 12;
+		while (bits_log2 < 30 && (1ull << bits_log2) < 16ull * n) ++bits_log2;
+		if (filter_log2_req >= 10 && filter_log2_req <= 30) bits_log2 = (uint32_t) filter_log2_req;
+		c->block_log2 = bits_log2 - 6;
+		blocks.assign(1ull << c->block_log2, 0ull);
+		const uint32_t blk_shift = 32 - c->block_log2;
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint64_t x = c->canon[i];
+			uint64_t rc = 0;
+			for (int b = 0; b < NTSM_FAST_K; ++b) rc |= (3ull - ((x >> (2 * b)) & 3ull)) << (2 * (NTSM_FAST_K - 1 - b));
+			uint32_t mz = 0xFFFFFFFFu;
+			for (int j = 0; j < NTSM_FAST_W; ++j) {
+				const uint32_t sub = (uint32_t) (x >> (2 * j)) & 0xFFFFFFu;
+				uint32_t rsub = 0;
+				for (int b = 0; b < NTSM_FAST_M; ++b) rsub |= (3u - ((sub >> (2 * b)) & 3u)) << (2 * (NTSM_FAST_M - 1 - b));
+				mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
+			}
+			const uint32_t kb = ntsm_kmer_bits((uint32_t) (x >> 6), (uint32_t) (rc >> 6));
+			blocks[ntsm_block_of(mz, blk_shift)] |= (1ull << (kb & 31u)) | (1ull << (32u + ((kb >> 5) & 31u)));
+		}
+	}
 	/* upload */
+	if (c->d_blocks) (void) hipFree(c->d_blocks);
+	c->d_blocks = nullptr;
+	if (!blocks.empty()) {
+		HIPCHK(hipMalloc(&c->d_blocks, blocks.size() * sizeof(unsigned long long)));
+		HIPCHK(hipMemcpy(c->d_blocks, blocks.data(), blocks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+	}
 	if (c->d_filter) (void) hipFree(c->d_filter);
 	if (c->d_keys) (void) hipFree(c->d_keys);
 	if (c->d_slot_counts) (void) hipFree(c->d_slot_counts);
@@ -423,6 +667,10 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.fshift = 32 - c->filter_log2;
 	p.bshift = 32 - c->bucket_log2;
 	p.lut = c->d_lut;
+	p.lut64 = c->d_lut64;
+	p.blocks = c->d_blocks;
+	p.blk_shift = 32 - c->block_log2;
+	const bool fast = c->k == NTSM_FAST_K && c->d_blocks && c->kernel_variant != 1 && c->block_log2 >= 1;
 	uint64_t grid = c->grid_blocks > 0 ? (uint64_t) c->grid_blocks : (uint64_t) c->n_cu * 4;
 	if (grid > p.n_tiles) grid = p.n_tiles;
 	int ev = -1;
@@ -438,7 +686,11 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		}
 		HIPCHK(hipEventRecord(c->ev_a[ev], st));
 	}
-	if (per_read)
+	if (fast && per_read)
+		hipLaunchKernelGGL((ntsm_count_k19_kernel<true>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
+	else if (fast)
+		hipLaunchKernelGGL((ntsm_count_k19_kernel<false>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
+	else if (per_read)
 		hipLaunchKernelGGL((ntsm_count_kernel<kTileC, true>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
 	else
 		hipLaunchKernelGGL((ntsm_count_kernel<kTileC, false>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
@@ -634,6 +886,13 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 	auto fail = [&](int code) { ntsm_destroy(c); return code; };
 	if (hipMalloc(&c->d_lut, 256) != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (hipMemcpy(c->d_lut, lut, 256, hipMemcpyHostToDevice) != hipSuccess) return fail(NTSM_ERR_HIP);
+	{
+		uint2 lut64[256];
+		for (int i = 0; i < 256; ++i)
+			lut64[i] = lut[i] < 4 ? make_uint2((uint32_t) lut[i] << 26, 3u - lut[i]) : make_uint2(0u, 0x80000003u);
+		if (hipMalloc(&c->d_lut64, sizeof lut64) != hipSuccess) return fail(NTSM_ERR_HIP);
+		if (hipMemcpy(c->d_lut64, lut64, sizeof lut64, hipMemcpyHostToDevice) != hipSuccess) return fail(NTSM_ERR_HIP);
+	}
 	if (hipMalloc(&c->d_totals, 4 * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (hipMalloc(&c->d_vec, ((uint64_t) n_kmers + 4) * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
@@ -660,7 +919,7 @@ void ntsm_destroy(ntsm_ctx *c)
 		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
 		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
 	}
-	void *ptrs[] = { c->d_filter, c->d_keys, c->d_slot_counts, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
+	void *ptrs[] = { c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_counts, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
 	for (void *p : ptrs) if (p) (void) hipFree(p);
 	delete c;
 }
@@ -886,6 +1145,15 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 }
 
 void *ntsm_stream(ntsm_ctx *c) { return c ? (void *) c->rstream : nullptr; }
+
+int ntsm_set_kernel(ntsm_ctx *c, int variant)
+{
+	if (!c || variant < 0 || variant > 1) return NTSM_ERR_ARG;
+	int rc = ntsm_sync(c, nullptr);
+	if (rc) return rc;
+	c->kernel_variant = variant;
+	return NTSM_OK;
+}
 
 /* One process driving n GPUs: RCCL SUM of every context's dense count vector + totals over xGMI.
  * SUM (not MAX): the per-site maxima are taken on the host from the summed per-k-mer counts,

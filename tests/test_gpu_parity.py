@@ -138,17 +138,22 @@ def test_random_reads_vs_oracle_n10(nt, n10):
     ends = s.read_end(n)
     fp = OracleFP(path)
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)   # one long "read": terminators reset windows
-    ctx = nt.Context(sites.keys)
-    half = (n // 2) * s.stride
-    ctx.submit(bases[:half], ends[:n // 2])                                # two batches -> both staging slots
-    ctx.submit(bases[half:], ends[n // 2:] - np.uint64(half))
-    t = ctx.sync()
     _, _, ocnt = fp.kmers()
-    assert np.array_equal(ctx.counts(), ocnt)
-    assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
-    assert t.total_bases == n * s.read_len and t.reads_consumed == n
-    assert t.total_hits > 1000
-    ctx.close()
+    # kernel variants (0 = minimizer-blocked fast path, 1 = generic) and filter sizes must all agree
+    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18)):
+        ctx = nt.Context(sites.keys)
+        ctx.set_kernel(variant)
+        if flog:
+            ctx.set_tuning(flog, 0)
+        half = (n // 2) * s.stride
+        ctx.submit(bases[:half], ends[:n // 2])                            # two batches -> both staging slots
+        ctx.submit(bases[half:], ends[n // 2:] - np.uint64(half))
+        t = ctx.sync()
+        assert np.array_equal(ctx.counts(), ocnt), (variant, flog)
+        assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
+        assert t.total_bases == n * s.read_len and t.reads_consumed == n
+        assert t.total_hits > 1000
+        ctx.close()
 
 
 def test_resident_path_properties_at_scale(nt, n10):
@@ -194,6 +199,7 @@ def test_resident_path_properties_at_scale(nt, n10):
     cut = 7_000_001 * s.stride
     ctx.count_resident(d_bases.data_ptr(), cut, 0, 7_000_001)
     rest = d_bases[cut:].clone()                    # re-based copy keeps 16-byte alignment of the pointer
+    torch.cuda.synchronize()                        # torch's stream wrote it; the library counts on its own stream
     ctx.count_resident(rest.data_ptr(), rest.numel(), 0, n - 7_000_001)
     assert np.array_equal(ctx.counts(), c1) and ctx.sync().total_kmers == t1.total_kmers
     # reverse complement of the whole stream: same canonical k-mers, same counts
@@ -204,6 +210,7 @@ def test_resident_path_properties_at_scale(nt, n10):
     if rc is None:
         part = d_bases[:3_000_000 * s.stride]
         rc = lut[part.flip(0).long()].contiguous()
+        torch.cuda.synchronize()
         ctx.reset(); ctx.count_resident(part.data_ptr(), part.numel(), 0, 3_000_000); fwd = ctx.counts(); tf = ctx.sync()
         ctx.reset(); ctx.count_resident(rc.data_ptr(), rc.numel(), 0, 3_000_000); rev = ctx.counts(); tr = ctx.sync()
         assert np.array_equal(fwd, rev) and tf.total_kmers == tr.total_kmers and tf.total_hits == tr.total_hits
