@@ -23,7 +23,7 @@ def _load(name):
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-hip_lib = _load("libntsm_hip.so")
+hip_lib = _load(os.environ.get("NTSM_HIP_LIB", "libntsm_hip.so"))   # env override: A/B builds of the same ABI
 host_lib = _load("libntsm_host.so")
 synth_lib = _load("libntsm_synth.so")
 

@@ -49,13 +49,21 @@ NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC
 NTSM_DHD uint32_t ntsm_mmer_hash(uint32_t cm)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return __umul24(cm, 0x9E3779u);
+	return (uint32_t) __umul24(cm, 0x9E3779u);
 #else
 	return (uint32_t) ((uint64_t) cm * 0x9E3779u);
 #endif
 }
-/* filter block of a minimizer value */
-NTSM_DHD uint32_t ntsm_block_of(uint32_t mz, uint32_t blk_shift) { return (mz * 0x9E3779B1u) >> blk_shift; }
+/* filter block of a minimizer value: 24x24-bit multiply (full rate on CDNA) of the low 24 bits of the
+ * order hash -- a bijective image of the 12-mer that the min-selection leaves unbiased */
+NTSM_DHD uint32_t ntsm_block_of(uint32_t mz, uint32_t blk_shift)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (uint32_t) __umul24(mz, 0xC2B2AFu) >> blk_shift;    /* __umul24 is declared int in HIP: shift unsigned */
+#else
+	return (uint32_t) ((uint64_t) (mz & 0xFFFFFFu) * 0xC2B2AFu) >> blk_shift;
+#endif
+}
 /* Two filter bits per site k-mer, one in each 32-bit half of the block: bit (h & 31) of the low
  * word and bit ((h >> 5) & 31) of the high word.  fh / rh are the top 32 bits of the 38-bit forward
  * and reverse-complement codes (code >> 6): together they cover all 19 bases, and the sum is
@@ -86,7 +94,7 @@ struct NtsmCountParams {
 	uint32_t kmask;                    /* low k bits set: window validity */
 	uint32_t fshift, bshift;           /* bit index = h1 >> fshift ; bucket = h >> bshift */
 	const uint8_t *lut;                /* 256-byte base table, vendor/KseqHashIterator.hpp:114-127 */
-	const uint2 *lut64;                /* fast path: per byte { code << 26, (3 - code) | invalid << 31 } */
+	const uint2 *lut64;                /* fast path: per byte { code, (3 - code) | invalid << 31 } */
 	const unsigned long long *blocks;  /* k = 19 fast path: minimizer-addressed 64-bit filter blocks */
 	uint32_t blk_shift;                /* block index = (mz * C) >> blk_shift */
 };

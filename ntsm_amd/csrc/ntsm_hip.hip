@@ -40,6 +40,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr uint32_t kN4 = 0x4E4E4E4Eu;      /* "NNNN" */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint4 ntsm_load_vec(const NtsmCountParams &p, long long o)
 {
@@ -205,6 +206,9 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 #ifndef NTSM_FAST_WAVES
 #define NTSM_FAST_WAVES 4                              /* waves per SIMD the register budget is held to */
 #endif
+#ifndef NTSM_FAST_PIPELINE
+#define NTSM_FAST_PIPELINE 0
+#endif
 constexpr int kFastC = 128;
 constexpr int kQueueCap = 64 + 8 * 64;                 /* < 64 left over + one 8-position burst */
 
@@ -219,7 +223,7 @@ __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
 template <bool PER_READ>
 __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kernel(const NtsmCountParams p)
 {
-	constexpr int C = kFastC, VPT = C / 16;
+	constexpr int C = kFastC, VPT = C / 16, NB = C / 8;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * C];
 	__shared__ uint2 lut64[256];
 	__shared__ uint16_t queue_all[kThreads / 64][kQueueCap];
@@ -228,6 +232,9 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 	uint16_t *queue = queue_all[t >> 6];
 	lut64[t] = p.lut64[t];
 	const uint32_t bshift = p.bshift, blk_shift = p.blk_shift;
+	/* buffer resource over the filter blocks: one instruction per load, 32-bit byte offset */
+	const __amdgpu_buffer_rsrc_t blk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+			const_cast<unsigned long long *>(p.blocks), 0, (int) (8u << (32 - blk_shift)), 0x00020000);
 	uint32_t nk = 0, nh = 0;
 
 	for (unsigned long long ti = blockIdx.x; ti < p.n_tiles; ti += gridDim.x) {
@@ -245,40 +252,34 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 		}
 		__syncthreads();
 
-		/* 38-bit forward / reverse-complement codes kept LEFT-aligned in 64 bits (code << 26):
-		 * the forward code drops its oldest base off the top by itself, the reverse code lets old
-		 * bases fall below bit 26 where nothing reads them -- 2 ops each per base, no masks. */
-		uint32_t FH = 0, FL = 0, RH = 0, RL = 0, inv = 0xFFFFFFFFu;
+		/* Rolling state: F = 2-bit codes of the last 16 bases (newest lowest), R = reverse complement
+		 * of the last 16 bases (complement of the newest base on top), inv = shift register of
+		 * "invalid base" flags.  One op each per base; the 19-mer's two strands are covered by
+		 * F three positions ago (its first 16 bases) and the current R (its last 16, reversed). */
+		uint32_t F = 0, R = 0, inv = 0xFFFFFFFFu;
 		uint32_t sprev[8];                                  /* suffix minima of the previous 8-block, [1..7] used */
+		uint32_t fc0, fc1, fc2;                             /* F at the three positions before the current block */
 		uint32_t qn = 0;                                    /* wave-uniform queue fill */
-#define NTSM_ROLL19(byte_)                                                                \
+#define NTSM_STEP(e_)                                                                     \
 		{                                                                                 \
-			const uint2 e_ = lut64[(byte_)];                                              \
-			FH = __builtin_amdgcn_alignbit(FH, FL, 30);                                   \
-			FL = (FL << 2) | e_.x;                                                        \
-			RL = __builtin_amdgcn_alignbit(RH, RL, 2);                                    \
-			RH = __builtin_amdgcn_alignbit(e_.y, RH, 2);                                  \
-			inv = __builtin_amdgcn_alignbit(inv, e_.y, 31);                               \
-		}
-#define NTSM_ROLL19E(e_)                                                                  \
-		{                                                                                 \
-			FH = __builtin_amdgcn_alignbit(FH, FL, 30);                                   \
-			FL = (FL << 2) | (e_).x;                                                      \
-			RL = __builtin_amdgcn_alignbit(RH, RL, 2);                                    \
-			RH = __builtin_amdgcn_alignbit((e_).y, RH, 2);                                \
+			F = (F << 2) | (e_).x;                                                        \
+			R = __builtin_amdgcn_alignbit((e_).y, R, 2);                                  \
 			inv = __builtin_amdgcn_alignbit(inv, (e_).y, 31);                             \
 		}
-#define NTSM_MMER_G() ntsm_mmer_hash(min(__builtin_amdgcn_alignbit(FH, FL, 26) & 0xFFFFFFu, RH >> 8))
+#define NTSM_MMER_G() ntsm_mmer_hash(min(F & 0xFFFFFFu, R >> 8))
 		{   /* warm-up: the 18 bytes in front of the chunk; 12-mer hashes of positions -7..-1 */
 			const uint4 v0 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 32));
 			const uint4 v1 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 16));
 			const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
-			uint32_t gw[8];
+			uint32_t gw[8], fh[32];
 #pragma unroll
 			for (int i = 14; i < 32; ++i) {
-				NTSM_ROLL19((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu)
+				const uint2 e = lut64[(w[i >> 2] >> ((i & 3) * 8)) & 0xFFu];
+				NTSM_STEP(e)
+				fh[i] = F;
 				if (i >= 25) gw[i - 24] = NTSM_MMER_G();     /* i = 25..31 -> block index 1..7 */
 			}
+			fc0 = fh[29]; fc1 = fh[30]; fc2 = fh[31];
 			sprev[7] = gw[7];
 #pragma unroll
 			for (int i = 6; i >= 1; --i) sprev[i] = min(gw[i], sprev[i + 1]);
@@ -292,23 +293,31 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				qn -= n;
 				if ((uint32_t) lane < n) {
 					const int off = queue[qn + lane];            /* tile offset of the window's last base */
-					uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+					/* the 19 bytes off-18 .. off: six aligned dwords (a dword never straddles a swizzled
+					 * 16-byte slot), then a byte funnel shift */
+					const int x0 = off - 18 + C;                 /* +C: row 0 is the halo row */
+					uint32_t d6[6], by[5];
+#pragma unroll
+					for (int q = 0; q < 6; ++q) {
+						int xd = (x0 & ~3) + 4 * q;
+						xd = xd > (kThreads + 1) * C - 4 ? (kThreads + 1) * C - 4 : xd;
+						d6[q] = *reinterpret_cast<const uint32_t *>(tile + ntsm_tile_addr(xd >> 7, xd & (C - 1)));
+					}
+#pragma unroll
+					for (int k = 0; k < 5; ++k) by[k] = __builtin_amdgcn_alignbyte(d6[k + 1], d6[k], (uint32_t) (x0 & 3));
+					/* pack the forward code (first base on top): 3 bases in the high word, 16 in the low */
 					uint32_t cc[19];
 #pragma unroll
-					for (int j = 0; j < 19; ++j) {                /* 19 independent LDS reads, then 19 table reads */
-						const int x = off - 18 + j + C;           /* +C: row 0 is the halo row */
-						cc[j] = tile[ntsm_tile_addr(x >> 7, x & (C - 1))];
-					}
+					for (int k = 0; k < 19; ++k) cc[k] = lut64[(by[k >> 2] >> ((k & 3) * 8)) & 0xFFu].x;
+					uint32_t a_hi = (cc[0] << 4) | (cc[1] << 2) | cc[2], a_lo = 0;
 #pragma unroll
-					for (int j = 0; j < 19; ++j) cc[j] = lut64[cc[j]].y & 3u;   /* 3 - code */
-#pragma unroll
-					for (int j = 0; j < 19; ++j) {
-						const uint32_t c3_ = cc[j], c_ = 3u - c3_;
-						a_hi = ((a_hi << 2) | (a_lo >> 30)) & 0x3Fu;
-						a_lo = (a_lo << 2) | c_;
-						b_lo = (b_lo >> 2) | (b_hi << 30);
-						b_hi = (b_hi >> 2) | (c3_ << 4);
-					}
+					for (int k = 3; k < 19; ++k) a_lo = (a_lo << 2) | cc[k];
+					/* reverse complement: reverse the 64 bits, swap the bits of each pair back, complement, align */
+					uint32_t r_hi = __builtin_bitreverse32(a_lo), r_lo = __builtin_bitreverse32(a_hi);
+					r_hi = ((r_hi & 0x55555555u) << 1) | ((r_hi >> 1) & 0x55555555u);
+					r_lo = ((r_lo & 0x55555555u) << 1) | ((r_lo >> 1) & 0x55555555u);
+					const unsigned long long rv = (~(((unsigned long long) r_hi << 32) | r_lo)) >> 26;
+					const uint32_t b_lo = (uint32_t) rv, b_hi = (uint32_t) (rv >> 32);
 					const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
 					const uint32_t klo = lt ? a_lo : b_lo, khi = lt ? a_hi : b_hi;
 					const uint32_t fo = ntsm_fold(((unsigned long long) khi << 32) | klo);
@@ -334,59 +343,83 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			}
 		};
 
-#pragma unroll 1
-		for (int b8 = 0; b8 < C / 8; ++b8) {                   /* 8 positions per step = one sliding-min block */
-			const uint2 v = *reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, b8 * 8));
+		/* Phase A of one 8-position block: roll, 12-mer order hashes, sliding minimum, k-mer bit hash;
+		 * decides per position whether the minimizer changed (nd) and issues the 8 filter-block loads
+		 * (lanes that keep their block all read block 0: one request per wave instruction). */
+		struct BlockState { uint32_t kb[8]; bool ok[8], nd[8]; uint2 bl[8]; };
+		auto phase_a = [&](const uint2 v, BlockState &B) {
 			const uint32_t w[2] = { v.x, v.y };
-			uint32_t mz[8], kb[8], gg[8], idx[8], pm = 0xFFFFFFFFu;
-			uint32_t okm = 0, needm = 0;                        /* per-lane bit j: window j valid / block j fetched */
-			/* phase A: roll, 12-mer hashes, sliding minimum, k-mer bit hash, block index */
-			uint2 e8[8];                                        /* the 8 table reads issue together, ahead of the dependent roll chain */
+			uint2 e8[8];
 #pragma unroll
 			for (int j = 0; j < 8; ++j) e8[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
+			uint32_t gg[8], fh[8], off[8], pm = 0xFFFFFFFFu;
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
-				NTSM_ROLL19E(e8[j])
+				NTSM_STEP(e8[j])
+				fh[j] = F;
 				gg[j] = NTSM_MMER_G();
 				pm = min(pm, gg[j]);
-				mz[j] = j < 7 ? min(sprev[j + 1], pm) : pm;
-				kb[j] = ntsm_kmer_bits(FH, RH);
-				const bool ok = (inv & 0x7FFFFu) == 0;
-				const bool nd = ok && mz[j] != cur_mz;
-				okm |= ok ? (1u << j) : 0u;
-				needm |= nd ? (1u << j) : 0u;
-				idx[j] = nd ? ntsm_block_of(mz[j], blk_shift) : 0u;   /* lanes that keep their block all read block 0 */
-				cur_mz = nd ? mz[j] : cur_mz;
+				const uint32_t mz = j < 7 ? min(sprev[j + 1], pm) : pm;
+				B.kb[j] = ntsm_kmer_bits(j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)), R);
+				/* plain & (no short circuit): keeps this straight-line code instead of exec-masked regions */
+				B.ok[j] = (inv & 0x7FFFFu) == 0;
+				B.nd[j] = B.ok[j] & (mz != cur_mz);
+				const uint32_t boff = ntsm_block_of(mz, blk_shift) << 3;
+				off[j] = B.nd[j] ? boff : 0u;
+				cur_mz = B.nd[j] ? mz : cur_mz;
+				nk += B.ok[j] ? 1u : 0u;
 			}
+			fc0 = fh[5]; fc1 = fh[6]; fc2 = fh[7];
 			sprev[7] = gg[7];
 #pragma unroll
 			for (int j = 6; j >= 1; --j) sprev[j] = min(gg[j], sprev[j + 1]);
-			nk += (uint32_t) __popc(okm);
-			/* phase B: eight unconditional 8-byte loads in flight together (one L2 request per changed minimizer) */
-			uint2 bl[8];
 #pragma unroll
-			for (int j = 0; j < 8; ++j) bl[j] = *reinterpret_cast<const uint2 *>(p.blocks + idx[j]);
-			/* phase C: bit tests, queue the positives */
+			for (int j = 0; j < 8; ++j) {                      /* buffer loads: 32-bit offset, no 64-bit address math */
+				const u32x2 bv = __builtin_amdgcn_raw_buffer_load_b64(blk_rsrc, (int) off[j], 0, 0);
+				B.bl[j] = make_uint2(bv.x, bv.y);
+			}
+		};
+		/* Phase C: two-bit test against the (possibly just fetched) block; positives go to the queue */
+		auto phase_c = [&](const BlockState &B, const int pos0) {
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
-				const bool nd = (needm >> j) & 1u;
-				cur_lo = nd ? bl[j].x : cur_lo;
-				cur_hi = nd ? bl[j].y : cur_hi;
-				const bool pass = ((cur_lo >> (kb[j] & 31u)) & (cur_hi >> ((kb[j] >> 5) & 31u)) & (okm >> j) & 1u) != 0;
+				cur_lo = B.nd[j] ? B.bl[j].x : cur_lo;
+				cur_hi = B.nd[j] ? B.bl[j].y : cur_hi;
+				const bool pass = B.ok[j] & (((cur_lo >> (B.kb[j] & 31u)) & (cur_hi >> ((B.kb[j] >> 5) & 31u)) & 1u) != 0);
 				const unsigned long long m = __ballot(pass);
 				if (m) {
 					if (pass) {
 						const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-						queue[at] = (uint16_t) (t * C + b8 * 8 + j);
+						queue[at] = (uint16_t) (pos0 + j);
 					}
 					qn += (uint32_t) __popcll(m);
 				}
 			}
 			if (qn >= 64) drain(false);
+		};
+
+#if NTSM_FAST_PIPELINE
+		/* software pipeline: block b+1's phase A (and its loads) run before block b's phase C, so every
+		 * filter load has a full block of independent work to hide behind */
+		BlockState S0, S1;
+		phase_a(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, 0)), S0);
+#pragma unroll 1
+		for (int b = 0; b < NB; b += 2) {
+			phase_a(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, (b + 1) * 8)), S1);
+			phase_c(S0, t * C + b * 8);
+			if (b + 2 < NB) phase_a(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, (b + 2) * 8)), S0);
+			phase_c(S1, t * C + b * 8 + 8);
 		}
+#else
+		BlockState S;
+#pragma unroll 1
+		for (int b = 0; b < NB; ++b) {
+			phase_a(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, b * 8)), S);
+			phase_c(S, t * C + b * 8);
+		}
+#endif
 		drain(true);
-#undef NTSM_ROLL19
-#undef NTSM_ROLL19E
+#undef NTSM_STEP
 #undef NTSM_MMER_G
 	}
 #pragma unroll
@@ -613,6 +646,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	HIPCHK(hipMemcpy(c->d_keys, keys.data(), c->n_slots * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(c->d_slot_counts, 0, c->n_slots * sizeof(uint64_t)));
 	if (n) HIPCHK(hipMemcpy(c->d_slot_of, c->slot_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIPCHK(hipDeviceSynchronize());                      /* tables and zeroed counters visible before any stream uses them */
 	return NTSM_OK;
 }
 
@@ -889,12 +923,13 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 	{
 		uint2 lut64[256];
 		for (int i = 0; i < 256; ++i)
-			lut64[i] = lut[i] < 4 ? make_uint2((uint32_t) lut[i] << 26, 3u - lut[i]) : make_uint2(0u, 0x80000003u);
+			lut64[i] = lut[i] < 4 ? make_uint2((uint32_t) lut[i], 3u - lut[i]) : make_uint2(0u, 0x80000003u);
 		if (hipMalloc(&c->d_lut64, sizeof lut64) != hipSuccess) return fail(NTSM_ERR_HIP);
 		if (hipMemcpy(c->d_lut64, lut64, sizeof lut64, hipMemcpyHostToDevice) != hipSuccess) return fail(NTSM_ERR_HIP);
 	}
 	if (hipMalloc(&c->d_totals, 4 * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
+	if (hipDeviceSynchronize() != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (hipMalloc(&c->d_vec, ((uint64_t) n_kmers + 4) * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (hipStreamCreateWithFlags(&c->rstream, hipStreamNonBlocking) != hipSuccess) return fail(NTSM_ERR_HIP);
 	for (int i = 0; i < kTimingPool; ++i) {
@@ -1087,8 +1122,11 @@ int ntsm_reset(ntsm_ctx *c)
 	if (!c) return NTSM_ERR_ARG;
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
-	HIPCHK(hipMemset(c->d_slot_counts, 0, c->n_slots * sizeof(uint64_t)));
-	HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
+	/* on the context's own stream and waited for: a null-stream memset is not ordered against the
+	 * non-blocking streams the count kernels run on */
+	HIPCHK(hipMemsetAsync(c->d_slot_counts, 0, c->n_slots * sizeof(uint64_t), c->rstream));
+	HIPCHK(hipMemsetAsync(c->d_totals, 0, 4 * sizeof(uint64_t), c->rstream));
+	HIPCHK(hipStreamSynchronize(c->rstream));
 	c->total_bases = c->reads_consumed = 0;
 	c->early_stop = c->reduced = false;
 	return NTSM_OK;
