@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=float, default=float(os.environ.get("NTSM_BENCH_READS", 1e9)),
                     help="reads per GPU (default 1e9 = BASELINE.json configs[1])")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter-log2", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)

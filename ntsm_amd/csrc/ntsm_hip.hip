@@ -1168,7 +1168,7 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
 	c->grid_blocks = grid_blocks;
-	if (filter_log2_bits > 0 && (uint32_t) filter_log2_bits != c->filter_log2) {
+	if (filter_log2_bits > 0) {
 		/* counts are slot-indexed: keep them across the rebuild only if the table is untouched */
 		std::vector<uint64_t> saved(c->n_slots);
 		HIPCHK(hipMemcpy(saved.data(), c->d_slot_counts, c->n_slots * sizeof(uint64_t), hipMemcpyDeviceToHost));

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""End-to-end rates that are NOT bench.py's `value`:
+  (1) PCIe-inclusive: ntsm_submit from host memory (pinned double buffering, H2D + kernel overlapped);
+  (2) CLI: build/ntsmCount on a FASTQ file (single-threaded parse + staging + GPU)."""
+import os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import ntsm_amd
+
+n_sub = int(float(sys.argv[1])) if len(sys.argv) > 1 else 40_000_000
+n_cli = int(float(sys.argv[2])) if len(sys.argv) > 2 else 3_000_000
+tmp = tempfile.mkdtemp(prefix="ntsm_e2e_")
+sp = os.path.join(tmp, "sites.fa")
+s = ntsm_amd.SynthShort(20241218, 96287, read_seed=7, sites_path=sp)
+sites = ntsm_amd.Sites(sp)
+dev = torch.device("cuda:0")
+d_win = torch.from_numpy(s.windows).to(dev)
+d = torch.empty(n_sub * s.stride, dtype=torch.uint8, device=dev)
+s.device_fill(d_win.data_ptr(), 0, n_sub, d.data_ptr()); torch.cuda.synchronize()
+host = d.cpu().numpy(); del d
+ctx = ntsm_amd.Context(sites.keys)
+per = 400_000                                   # reads per batch (60 MB)
+ends = s.read_end(per)
+ctx.submit(host[:per * s.stride], ends); ctx.sync(); ctx.reset()
+t0 = time.perf_counter()
+for b in range(n_sub // per):
+    ctx.submit(host[b * per * s.stride:(b + 1) * per * s.stride], ends)
+t = ctx.sync(); dt = time.perf_counter() - t0
+print("submit path (host buffers, incl. memcpy to pinned + PCIe): %.1f Gbases/s (%d reads, %.2f s)" % (t.total_bases / dt / 1e9, n_sub, dt))
+ctx.close()
+fq = os.path.join(tmp, "reads.fq")
+t0 = time.perf_counter(); s.write_fastq(fq, 0, n_cli); print("wrote %s in %.1f s" % (fq, time.perf_counter() - t0))
+t0 = time.perf_counter()
+p = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", sp, fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+dt = time.perf_counter() - t0
+print("CLI end to end: %.2f s for %d reads -> %.3f Gbases/s (includes site-table build)" % (dt, n_cli, n_cli * 150 / dt / 1e9))
+print(p.stderr.decode()[-400:])
