@@ -133,6 +133,12 @@ def main():
         launch_s = kernel_ms / 1e3 / max(n_launch, 1)
         bytes_per_base = (READ_LEN + 8) / READ_LEN
         achieved = bases_per_step * bytes_per_base / launch_s / 1e9
+        traffic = None                          # PMC-derived bytes per launch (separate rocprofv3 --pmc passes, profiles/)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = tj["traffic_bytes_per_base"] * bases_per_step
+        except Exception:
+            pass
         out = {
             "metric": "bases/s through ntsmCount count path, 150 bp reads vs hs_n10_like (96287 sites)",
             "value": value, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -144,8 +150,11 @@ def main():
                        "reads_per_gpu": n_reads, "read_len": READ_LEN, "k": K, "n_sites": N_SITES,
                        "parallelism": "reads sharded over %d GPU(s); one RCCL SUM of per-k-mer counts per step" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ntsm_count_kernel", "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "fabric-side bytes/launch from FETCH_SIZE+WRITE_SIZE (profiles/r01_traffic.json): L2 misses "
+                                         "of filter/table served by the Infinity Cache + the stream; not HBM re-reads",
+                         "achieved_stream_only_GBs": bases_per_step * (READ_LEN + 1) / READ_LEN / launch_s / 1e9,
+                         "kernel": "ntsm_count_k19_kernel" if K == 19 and not args.kernel else "ntsm_count_kernel", "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
                          "algorithmic_bytes_per_base": bytes_per_base,
                          "kmer_probe_rate_per_s": totals.total_kmers / max(args.steps + args.warmup, 1) / launch_s},
             "check": {"total_kmers_per_step": totals.total_kmers // (args.steps + args.warmup) if world == 1 else None,
