@@ -299,3 +299,41 @@ class SynthShort:
         rc = SY.ntsm_synth_short_write_fastq(C.byref(self.params), _p(self.windows, u8p), r0, n_reads, os.fsencode(path))
         if rc:
             raise NtsmError("write_fastq failed: %d" % rc)
+
+
+class SynthLong:
+    """Seeded long-read workload (BASELINE.json configs[2]): log-normal lengths, implicit mini-genome with one
+    site window every `spacing` bases, substitution errors (ntsm_amd/csrc/synth.h)."""
+
+    def __init__(self, short: "SynthShort", read_seed=13, spacing=20000, mu=9.6, sigma=0.6, lo=200, hi=200000,
+                 p_sub=0.05, p_n=5e-4):
+        self.short, self.seed = short, read_seed
+        self.params = SynthLongParams()
+        SY.ntsm_synth_long_params(C.byref(self.params), read_seed, short.n_sites, spacing, p_sub, p_n)
+        self.qtable = np.zeros(257, dtype=np.uint32)
+        SY.ntsm_synth_long_qtable(mu, sigma, lo, hi, _p(self.qtable, u32p))
+
+    def layout(self, r0, n_reads):
+        ends = np.zeros(n_reads, dtype=np.uint64)
+        total = SY.ntsm_synth_long_layout(self.seed, _p(self.qtable, u32p), r0, n_reads, _p(ends, u64p))
+        return ends, int(total)
+
+    def host_bytes(self, r0, n_reads):
+        ends, total = self.layout(r0, n_reads)
+        out = np.zeros(total, dtype=np.uint8)
+        SY.ntsm_synth_long_fill_host(C.byref(self.params), _p(self.short.windows, u8p), _p(self.qtable, u32p), r0, n_reads,
+                                     _p(ends, u64p), _p(out, u8p))
+        return out, ends
+
+    def device_fill(self, d_windows_ptr, r0, n_reads, d_read_end_ptr, n_bytes, d_out_ptr, stream=None):
+        rc = SY.ntsm_synth_long_fill_device(C.byref(self.params), C.c_void_p(d_windows_ptr), None, r0, n_reads,
+                                            C.c_void_p(d_read_end_ptr), n_bytes, C.c_void_p(d_out_ptr),
+                                            C.c_void_p(stream) if stream else None)
+        if rc:
+            raise NtsmError("device fill failed: %d" % rc)
+
+    def write_fastq(self, path, r0, n_reads):
+        rc = SY.ntsm_synth_long_write_fastq(C.byref(self.params), _p(self.short.windows, u8p), _p(self.qtable, u32p), r0, n_reads,
+                                            os.fsencode(path))
+        if rc:
+            raise NtsmError("write_fastq failed: %d" % rc)

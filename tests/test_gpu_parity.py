@@ -276,3 +276,74 @@ def test_early_stop_resident_and_batched(nt, n10):
 def test_duplicate_keys_rejected(nt):
     with pytest.raises(nt.NtsmError):
         nt.Context(np.array([5, 9, 5], dtype=np.uint64), k=19)
+
+
+def test_long_reads_and_m_threshold(nt, n10, tmp_path):
+    """BASELINE.json configs[2] shape at small scale: ONT-like reads (N50 ~ 20 kb, 5 % errors) cut from a mini-genome;
+    device fill == host fill; resident counting == oracle; -m stop index/totals == oracle (resident and via the CLI)."""
+    import torch
+    s, sites, path = n10
+    L = nt.SynthLong(s, read_seed=13, spacing=2000)
+    n = 1500
+    bases, ends = L.host_bytes(0, n)
+    lens = np.diff(np.concatenate([[np.uint64(0)], ends + np.uint64(1)])) - 1
+    assert lens.min() >= 200 and lens.max() <= 200000 and 8000 < np.median(lens) < 25000
+    dev = torch.device("cuda:0")
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d_ends = torch.from_numpy(ends.view(np.int64)).to(dev)
+    d_bases = torch.empty(bases.size, dtype=torch.uint8, device=dev)
+    L.device_fill(d_win.data_ptr(), 0, n, d_ends.data_ptr(), bases.size, d_bases.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_bases.cpu().numpy(), bases)
+    full = OracleFP(path)
+    full.process_flat(bases, ends)
+    assert full.total_hits > 5000
+    ctx = nt.Context(sites.keys)
+    ctx.count_resident(d_bases.data_ptr(), bases.size, d_ends.data_ptr(), n)
+    t = ctx.sync()
+    assert np.array_equal(ctx.counts(), full.kmers()[2])
+    assert (t.total_kmers, t.total_hits, t.total_bases) == (full.total_kmers, full.total_hits, full.total_bases)
+    ctx.close()
+    # early stop in the middle of the stream, resident input (read_end on the device)
+    thr = full.total_hits // 2
+    cov = 2.0 * (thr + 0.5) / len(sites.keys)
+    fp = OracleFP(path, cov=cov)
+    fp.process_flat(bases, ends)
+    assert fp.early_term and 0 < fp.reads_processed < n
+    ctx = nt.Context(sites.keys, max_hits=thr)
+    ctx.count_resident(d_bases.data_ptr(), bases.size, d_ends.data_ptr(), n)
+    t = ctx.sync()
+    assert t.early_stop == 1 and t.reads_consumed == fp.reads_processed
+    assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases)
+    assert np.array_equal(ctx.counts(), fp.kmers()[2])
+    ctx.close()
+    # the CLI against the oracle CLI on the same FASTQ (gzip), -m given as on the command line
+    fq = str(tmp_path / "long.fq.gz")
+    L.write_fastq(fq, 0, 300)
+    for extra in ([], ["-m", "0.004"]):
+        a = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", path] + extra + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([os.path.join(ROOT, "oracle", "ntsm_oracle"), "-s", path] + extra + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert a.returncode == 0 and b.returncode == 0, a.stderr[-300:]
+        assert a.stdout == b.stdout
+        assert _summary(a.stderr) == _summary(b.stderr)
+    assert b"Reached desired" in a.stderr
+
+
+def test_large_site_set_regime(nt, tmp_path):
+    """BASELINE.json configs[4] regime at reduced size: 300k sites (4.8 M k-mers, 64 MiB key table, 8 MiB blocked
+    filter: beyond L2) -- counts and totals still equal the oracle's."""
+    s = nt.SynthShort(sites_seed=77, n_sites=300_000, read_seed=3, p_embed=0.3, sites_path=str(tmp_path / "big.fa"))
+    sites = nt.Sites(str(tmp_path / "big.fa"))
+    assert len(sites.keys) == s.n_kmers > 4_000_000
+    n = 150_000
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(str(tmp_path / "big.fa"))
+    fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)
+    for variant in (0, 1):
+        ctx = nt.Context(sites.keys)
+        ctx.set_kernel(variant)
+        ctx.submit(bases, ends)
+        t = ctx.sync()
+        assert np.array_equal(ctx.counts(), fp.kmers()[2])
+        assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
+        ctx.close()
