@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			for (int j = 0; j < 8; ++j) {
 				cur_lo = B.nd[j] ? B.bl[j].x : cur_lo;
 				cur_hi = B.nd[j] ? B.bl[j].y : cur_hi;
-				const bool pass = B.ok[j] & (((cur_lo >> (B.kb[j] & 31u)) & (cur_hi >> ((B.kb[j] >> 5) & 31u)) & 1u) != 0);
+				const bool pass = B.ok[j] & (((cur_lo >> NTSM_KBIT_LO(B.kb[j])) & (cur_hi >> NTSM_KBIT_HI(B.kb[j])) & 1u) != 0);
 				const unsigned long long m = __ballot(pass);
 				if (m) {
 					if (pass) {
@@ -623,7 +623,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 				mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
 			}
 			const uint32_t kb = ntsm_kmer_bits((uint32_t) (x >> 6), (uint32_t) (rc >> 6));
-			blocks[ntsm_block_of(mz, blk_shift)] |= (1ull << (kb & 31u)) | (1ull << (32u + ((kb >> 5) & 31u)));
+			blocks[ntsm_block_of(mz, blk_shift)] |= (1ull << NTSM_KBIT_LO(kb)) | (1ull << (32u + NTSM_KBIT_HI(kb)));
 		}
 	}
 	/* upload */
