@@ -284,7 +284,8 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 #pragma unroll
 			for (int i = 6; i >= 1; --i) sprev[i] = min(gw[i], sprev[i + 1]);
 		}
-		uint32_t cur_mz = NTSM_NO_MINIMIZER, cur_lo = 0, cur_hi = 0;
+		uint32_t mz_prev = 0, cur_lo = 0, cur_hi = 0;
+		bool ok_prev = false;                               /* nothing cached at the start of a chunk */
 
 		/* drain: look up queued positives, 64 at a time (or the remainder when `all`) */
 		auto drain = [&](bool all) {
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			uint2 e8[8];
 #pragma unroll
 			for (int j = 0; j < 8; ++j) e8[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
-			uint32_t gg[8], fh[8], off[8], pm = 0xFFFFFFFFu;
+			uint32_t gg[8], fh[8], idx[8], pm = 0xFFFFFFFFu;
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
 				NTSM_STEP(e8[j])
@@ -361,12 +362,14 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				pm = min(pm, gg[j]);
 				const uint32_t mz = j < 7 ? min(sprev[j + 1], pm) : pm;
 				B.kb[j] = ntsm_kmer_bits(j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)), R);
-				/* plain & (no short circuit): keeps this straight-line code instead of exec-masked regions */
+				/* plain & / | (no short circuit): keeps this straight-line code instead of exec-masked regions.
+				 * A lane (re)loads when its window is valid and either the minimizer differs from the previous
+				 * position's or the previous window was invalid (then no block is cached for it). */
 				B.ok[j] = (inv & 0x7FFFFu) == 0;
-				B.nd[j] = B.ok[j] & (mz != cur_mz);
-				const uint32_t boff = ntsm_block_of(mz, blk_shift) << 3;
-				off[j] = B.nd[j] ? boff : 0u;
-				cur_mz = B.nd[j] ? mz : cur_mz;
+				B.nd[j] = B.ok[j] & ((mz != mz_prev) | !ok_prev);
+				idx[j] = B.nd[j] ? (ntsm_block_of(mz, blk_shift) << 3) : 0xFFFFFFFFu;   /* out of range: returns 0, no memory request */
+				mz_prev = mz;
+				ok_prev = B.ok[j];
 				nk += B.ok[j] ? 1u : 0u;
 			}
 			fc0 = fh[5]; fc1 = fh[6]; fc2 = fh[7];
@@ -374,8 +377,8 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 #pragma unroll
 			for (int j = 6; j >= 1; --j) sprev[j] = min(gg[j], sprev[j + 1]);
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {                      /* buffer loads: 32-bit offset, no 64-bit address math */
-				const u32x2 bv = __builtin_amdgcn_raw_buffer_load_b64(blk_rsrc, (int) off[j], 0, 0);
+			for (int j = 0; j < 8; ++j) {                      /* buffer loads: 32-bit byte offset, range-checked by the descriptor */
+				const u32x2 bv = __builtin_amdgcn_raw_buffer_load_b64(blk_rsrc, (int) idx[j], 0, 0);
 				B.bl[j] = make_uint2(bv.x, bv.y);
 			}
 		};
