@@ -70,7 +70,8 @@ def main():
         sys.exit("bench.py needs an MI355X: the count path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("NTSM_FORCE_DIST"))     # force: exercise the RCCL path on one rank
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     n_reads = int(args.reads)
@@ -102,14 +103,14 @@ def main():
 
     def run_step():
         ctx.count_resident(d_bases.data_ptr(), n_bytes, 0, n_reads)
-        if world > 1:
+        if use_dist:
             merge_counts(ctx)
 
     for _ in range(args.warmup):
         run_step()
     ctx.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     ctx.set_timing(True)
     t0 = time.perf_counter()
@@ -117,13 +118,13 @@ def main():
         run_step()
     ctx.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = ctx.get_timing()
     totals = ctx.sync()
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -167,7 +168,7 @@ def main():
                 out["gpu_over_cpu"] = value / cb["value"]
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

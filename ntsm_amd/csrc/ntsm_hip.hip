@@ -206,6 +206,9 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 #ifndef NTSM_FAST_WAVES
 #define NTSM_FAST_WAVES 4                              /* waves per SIMD the register budget is held to */
 #endif
+#ifndef NTSM_FAST_BRANCHLESS_PUSH
+#define NTSM_FAST_BRANCHLESS_PUSH 0
+#endif
 #ifndef NTSM_FAST_PIPELINE
 #define NTSM_FAST_PIPELINE 0
 #endif
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 	constexpr int C = kFastC, VPT = C / 16, NB = C / 8;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * C];
 	__shared__ uint2 lut64[256];
-	__shared__ uint16_t queue_all[kThreads / 64][kQueueCap];
+	__shared__ uint16_t queue_all[kThreads / 64][kQueueCap + 64 * NTSM_FAST_BRANCHLESS_PUSH];
 	const int t = threadIdx.x;
 	const int lane = t & 63;
 	uint16_t *queue = queue_all[t >> 6];
@@ -390,6 +393,12 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				cur_hi = B.nd[j] ? B.bl[j].y : cur_hi;
 				const bool pass = B.ok[j] & (((cur_lo >> NTSM_KBIT_LO(B.kb[j])) & (cur_hi >> NTSM_KBIT_HI(B.kb[j])) & 1u) != 0);
 				const unsigned long long m = __ballot(pass);
+#if NTSM_FAST_BRANCHLESS_PUSH
+				/* every lane stores: positives at their compacted slot, the rest into a per-lane trash slot */
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+				queue[pass ? qn + rank : (uint32_t) (kQueueCap + lane)] = (uint16_t) (pos0 + j);
+				qn += (uint32_t) __popcll(m);
+#else
 				if (m) {
 					if (pass) {
 						const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
@@ -397,6 +406,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 					}
 					qn += (uint32_t) __popcll(m);
 				}
+#endif
 			}
 			if (qn >= 64) drain(false);
 		};

@@ -347,3 +347,32 @@ def test_large_site_set_regime(nt, tmp_path):
         assert np.array_equal(ctx.counts(), fp.kmers()[2])
         assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
         ctx.close()
+
+
+def test_merge_counts_single_rank_roundtrip(nt, n10):
+    """The RCCL merge plumbing on one rank: the library's device vector wrapped zero-copy as a torch tensor,
+    imported back, reports the same counts/totals (ntsm_counts_device / ntsm_import_reduced)."""
+    import torch
+    from ntsm_amd.dist import merge_counts, _DeviceVector
+    s, sites, path = n10
+    n = 50_000
+    ctx = nt.Context(sites.keys)
+    ctx.submit(s.host_bytes(0, n), s.read_end(n))
+    t0, c0 = ctx.sync(), ctx.counts()
+    ptr, words = ctx.counts_device()
+    vec = torch.as_tensor(_DeviceVector(ptr, words), device="cuda")
+    assert words == len(sites.keys) + 4
+    host = vec.cpu().numpy().view(np.uint64)
+    assert np.array_equal(host[:-4], c0)
+    assert list(host[-4:]) == [t0.total_kmers, t0.total_hits, t0.total_bases, t0.reads_consumed]
+    vec *= 2                                             # stand-in for a 2-rank SUM of identical shards
+    torch.cuda.synchronize()
+    ctx.import_reduced()
+    t1 = ctx.sync()
+    assert np.array_equal(ctx.counts(), 2 * c0)
+    assert (t1.total_kmers, t1.total_hits, t1.total_bases, t1.reads_consumed) == (2 * t0.total_kmers, 2 * t0.total_hits, 2 * t0.total_bases, 2 * t0.reads_consumed)
+    merge_counts(ctx)                                    # no process group: idempotent on an already merged context
+    assert np.array_equal(ctx.counts(), 2 * c0)
+    ctx.submit(s.host_bytes(0, 10), s.read_end(10))      # new local work invalidates the merged view
+    assert ctx.sync().reads_consumed == n + 10
+    ctx.close()
