@@ -99,7 +99,7 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 				int rc = ntsm_staging_acquire(m_ctx, &m_bases, &m_capBytes, &m_readEnd, &m_capReads);
 				if (rc) die(rc, "cannot acquire staging");
 			}
-			memcpy(m_bases + m_fill, rd.seq().data(), len);
+			memcpy(m_bases + m_fill, rd.seq_data(), len);
 			m_fill += len;
 			m_bases[m_fill] = 'N';                               /* read terminator */
 			m_readEnd[m_nReads++] = m_fill;

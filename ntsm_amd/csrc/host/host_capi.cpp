@@ -56,7 +56,7 @@ int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint
 	std::vector<uint64_t> e;
 	int64_t l;
 	while ((l = rd.next()) >= 0) {
-		b.insert(b.end(), rd.seq().begin(), rd.seq().begin() + l);
+		b.insert(b.end(), rd.seq_data(), rd.seq_data() + l);
 		e.push_back(b.size());
 		b.push_back('N');
 	}

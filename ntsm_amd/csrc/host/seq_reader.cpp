@@ -76,6 +76,61 @@ int64_t SeqReader::until(bool line, std::vector<char> &dst, int *delim)
 	return (int64_t) dst.size();
 }
 
+/* One whole record with plain '\n' line ends inside the buffer:
+ *   FASTQ: header \n SEQ \n +... \n QUAL \n   with |QUAL| == |SEQ| >= 1
+ *   FASTA: header \n SEQ \n  followed by a line that starts a new record ('>' or '@')
+ * Anything else (CR, wrapped lines, empty sequence, record cut by the buffer end, end of file)
+ * is left to the general path, which reproduces kseq byte for byte. */
+bool SeqReader::fast_record(int64_t *len)
+{
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		const unsigned char *b = buf_.data();
+		const unsigned char *p = b + beg_, *e = b + end_;
+		const unsigned char *nl1 = p < e ? (const unsigned char *) memchr(p, '\n', (size_t) (e - p)) : nullptr;
+		const unsigned char *q = nl1 ? nl1 + 1 : nullptr;
+		const unsigned char *nl2 = (q && q < e) ? (const unsigned char *) memchr(q, '\n', (size_t) (e - q)) : nullptr;
+		if (nl2 && nl2 + 1 < e) {
+			const int64_t slen = nl2 - q;
+			if (slen < 1 || q[0] == '>' || q[0] == '@' || q[0] == '+' || nl2[-1] == '\r' || nl1[-1 + (nl1 == p)] == '\r') return false;
+			const unsigned char c3 = nl2[1];
+			const unsigned char *name_end = p;
+			while (name_end < nl1 && !isspace(*name_end)) ++name_end;
+			if (c3 == '>' || c3 == '@') {                       /* single-line FASTA record */
+				name_.assign((const char *) p, (size_t) (name_end - p));
+				seq_ptr_ = (const char *) q;
+				*len = slen;
+				pending_ = c3;
+				beg_ = (int) (nl2 + 2 - b);
+				return true;
+			}
+			if (c3 != '+') return false;
+			const unsigned char *nl3 = (const unsigned char *) memchr(nl2 + 1, '\n', (size_t) (e - (nl2 + 1)));
+			const unsigned char *u = nl3 ? nl3 + 1 : nullptr;
+			const unsigned char *nl4 = (u && u < e) ? (const unsigned char *) memchr(u, '\n', (size_t) (e - u)) : nullptr;
+			if (nl4) {
+				if (nl4 - u != slen || nl4[-1] == '\r') return false;
+				name_.assign((const char *) p, (size_t) (name_end - p));
+				seq_ptr_ = (const char *) q;
+				*len = slen;
+				pending_ = 0;
+				beg_ = (int) (nl4 + 1 - b);
+				return true;
+			}
+		}
+		/* record not complete in the buffer: slide the tail to the front and read more, once */
+		if (attempt == 1 || eof_ || end_ < 0) return false;
+		const int keep = end_ - beg_;
+		if (keep > kBuf / 2) return false;
+		memmove(buf_.data(), buf_.data() + beg_, (size_t) keep);
+		const int got = gzread(f_, buf_.data() + keep, (unsigned) (kBuf - keep));
+		beg_ = 0;
+		if (got < 0) { end_ = keep; return false; }              /* the general path will hit the error again */
+		if (got == 0) eof_ = true;
+		end_ = keep + got;
+	}
+	return false;
+}
+
 int64_t SeqReader::next()
 {
 	int c;
@@ -83,6 +138,10 @@ int64_t SeqReader::next()
 		while ((c = get()) >= 0 && c != '>' && c != '@') { }
 		if (c < 0) return c;
 		pending_ = c;
+	}
+	{
+		int64_t flen;
+		if (fast_record(&flen)) return flen;
 	}
 	seq_.clear();
 	qual_len_ = 0;
@@ -100,12 +159,14 @@ int64_t SeqReader::next()
 		until(true, seq_, nullptr);
 	}
 	if (c == '>' || c == '@') pending_ = c;
+	seq_ptr_ = seq_.data();
 	if (c != '+') return (int64_t) seq_.size();
 	while ((c = get()) >= 0 && c != '\n') { }
 	if (c == -1) return -2;
 	qual_.clear();
 	while (until(true, qual_, nullptr) >= 0 && qual_.size() < seq_.size()) { }
 	pending_ = 0;
+	seq_ptr_ = seq_.data();
 	if (qual_.size() != seq_.size()) return -2;
 	return (int64_t) seq_.size();
 }

@@ -35,11 +35,16 @@ public:
 	/* Next record: returns the sequence length (>= 0), -1 at end of file, -2 on a truncated
 	 * quality block, -3 on a stream error.  seq()/name() are valid until the next call. */
 	int64_t next();
-	const std::vector<char> &seq() const { return seq_; }
+	/* sequence bytes of the current record (length = next()'s return value); may point into the
+	 * read buffer (fast path) or into an internal vector (general path) */
+	const char *seq_data() const { return seq_ptr_; }
 	const std::string &name() const { return name_; }
 
 private:
-	static constexpr int kBuf = 1 << 18;
+	static constexpr int kBuf = 1 << 22;
+	/* Fast path for the common record shapes (4-line FASTQ, 2-line FASTA, no CR, record inside the
+	 * buffer): returns false when the record needs the general byte-by-byte path. */
+	bool fast_record(int64_t *len);
 	int get();                                           /* next byte, -1 EOF, -3 error */
 	/* append bytes up to (not including) the next '\n' (line = true) or isspace byte to dst;
 	 * returns <0 exactly when the reference's ks_getuntil2 would; *delim = byte that stopped it */
@@ -52,6 +57,7 @@ private:
 	bool eof_ = false;
 	int pending_ = 0;                                    /* header byte already consumed ('>' / '@'), 0 = none */
 	std::vector<char> seq_, qual_, scratch_;
+	const char *seq_ptr_ = nullptr;
 	std::string name_;
 	uint64_t qual_len_ = 0;
 };

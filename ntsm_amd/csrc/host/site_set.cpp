@@ -25,7 +25,7 @@ bool SiteSet::load(const std::string &path, unsigned kk, bool allow_dupes, std::
 		std::vector<std::vector<int64_t>> &side = is_ref ? ref : var;
 		side.emplace_back();
 		std::vector<int64_t> &list = side.back();
-		for_each_kmer(rd.seq().data(), (uint64_t) l, k, [&](uint64_t code, uint64_t pos) {
+		for_each_kmer(rd.seq_data(), (uint64_t) l, k, [&](uint64_t code, uint64_t pos) {
 			auto it = index.find(code);
 			if (it != index.end()) {
 				err << "Warning: " << rd.name() << " of " << (is_ref ? "REF" : "VAR")

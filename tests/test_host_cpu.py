@@ -144,3 +144,27 @@ def test_synth_generator_is_counter_based(nt, tmp_path):
     # the committed tiny fixture was produced by the same generator
     ref, _, _ = nt.flatten_file(os.path.join(G, "inputs", "reads2k.fq"))
     assert np.array_equal(ref[:50 * 151], whole)
+
+
+def test_reader_fast_path_across_buffer_refills(nt, tmp_path):
+    """Files larger than the reader's 4 MiB buffer: records straddling a refill, FASTQ and single-line FASTA,
+    plain and gzip -- same records as the oracle's kseq restatement."""
+    import gzip
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=21, p_embed=0.2)
+    fq = str(tmp_path / "big.fq")
+    s.write_fastq(fq, 0, 30000)                          # ~9.3 MB
+    raw = open(fq, "rb").read()
+    fa = str(tmp_path / "big.fa")
+    lines = raw.split(b"\n")
+    with open(fa, "wb") as f:                            # 2-line FASTA built from the same reads, last record unterminated
+        f.write(b"\n".join(b">" + lines[i][1:] + b"\n" + lines[i + 1] for i in range(0, len(lines) - 1, 4)))
+    gz = str(tmp_path / "big.fq.gz")
+    with gzip.open(gz, "wb", compresslevel=1) as f:
+        f.write(raw)
+    exp = s.host_bytes(0, 30000)
+    for path in (fq, fa, gz):
+        recs, rc = read_records(path)
+        bases, ends, last = nt.flatten_file(path)
+        assert last == rc == -1 and len(recs) == 30000 == len(ends)
+        assert bases.tobytes() == b"".join(x + b"N" for _, x in recs)
+        assert np.array_equal(bases, exp)

@@ -14,13 +14,13 @@ n_cli = int(float(sys.argv[2])) if len(sys.argv) > 2 else 3_000_000
 tmp = tempfile.mkdtemp(prefix="ntsm_e2e_")
 sp = os.path.join(tmp, "sites.fa")
 s = ntsm_amd.SynthShort(20241218, 96287, read_seed=7, sites_path=sp)
-sites = ntsm_amd.Sites(sp)
+t0 = time.perf_counter(); sites = ntsm_amd.Sites(sp); print("site load: %.2f s (%d k-mers)" % (time.perf_counter() - t0, len(sites.keys)))
 dev = torch.device("cuda:0")
 d_win = torch.from_numpy(s.windows).to(dev)
 d = torch.empty(n_sub * s.stride, dtype=torch.uint8, device=dev)
 s.device_fill(d_win.data_ptr(), 0, n_sub, d.data_ptr()); torch.cuda.synchronize()
 host = d.cpu().numpy(); del d
-ctx = ntsm_amd.Context(sites.keys)
+t0 = time.perf_counter(); ctx = ntsm_amd.Context(sites.keys); print("ntsm_create (tables + upload): %.2f s" % (time.perf_counter() - t0))
 per = 400_000                                   # reads per batch (60 MB)
 ends = s.read_end(per)
 ctx.submit(host[:per * s.stride], ends); ctx.sync(); ctx.reset()
@@ -32,6 +32,8 @@ print("submit path (host buffers, incl. memcpy to pinned + PCIe): %.1f Gbases/s 
 ctx.close()
 fq = os.path.join(tmp, "reads.fq")
 t0 = time.perf_counter(); s.write_fastq(fq, 0, n_cli); print("wrote %s in %.1f s" % (fq, time.perf_counter() - t0))
+t0 = time.perf_counter(); b_, e_, _ = ntsm_amd.flatten_file(fq); dt = time.perf_counter() - t0
+print("host parse only (SeqReader -> flat stream, 1 thread): %.2f s -> %.2f Gbases/s" % (dt, n_cli * 150 / dt / 1e9)); del b_, e_
 t0 = time.perf_counter()
 p = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", sp, fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
 dt = time.perf_counter() - t0
