@@ -37,6 +37,9 @@
 
 namespace {
 
+#ifndef NTSM_STREAM_NT
+#define NTSM_STREAM_NT 1                                /* read stream: non-temporal loads (read once) */
+#endif
 constexpr int kThreads = 256;
 constexpr uint32_t kN4 = 0x4E4E4E4Eu;      /* "NNNN" */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -46,7 +49,11 @@ __device__ __forceinline__ uint4 ntsm_load_vec(const NtsmCountParams &p, long lo
 {
 	uint4 r = make_uint4(kN4, kN4, kN4, kN4);
 	if (o + 16 > p.lo && o < p.hi) {
+#if NTSM_STREAM_NT
 		const u32x4 nt = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p.base + o));
+#else
+		const u32x4 nt = *reinterpret_cast<const u32x4 *>(p.base + o);
+#endif
 		r = make_uint4(nt.x, nt.y, nt.z, nt.w);
 		if (o < p.lo || o + 16 > p.hi) {                    /* first / last vector of the range */
 			uint32_t w[4] = { r.x, r.y, r.z, r.w };

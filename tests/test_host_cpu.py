@@ -168,3 +168,20 @@ def test_reader_fast_path_across_buffer_refills(nt, tmp_path):
         assert last == rc == -1 and len(recs) == 30000 == len(ends)
         assert bases.tobytes() == b"".join(x + b"N" for _, x in recs)
         assert np.array_equal(bases, exp)
+
+
+def test_host_code_under_asan_ubsan(built, tmp_path):
+    """Reader, site loader and report formatting over every golden input under AddressSanitizer + UBSan
+    (CPU build; GPU sanitizers are not available on this pool)."""
+    import subprocess
+    exe = str(tmp_path / "host_sanitize")
+    host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
+    srcs = [os.path.join(ROOT, "tools", "host_sanitize.cpp")] + [os.path.join(host, f) for f in ("seq_reader.cpp", "site_set.cpp", "report.cpp")]
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe] + srcs + ["-lz"], check=True)
+    reads = [p for p in INPUTS if not os.path.basename(p).startswith("sites")]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
+    for sites, k, dupes in (("sites200.fa", 19, 0), ("sites_dupes.fa", 19, 1), ("sites_dupes.fa", 19, 0), ("sites_odd.fa", 19, 0),
+                            ("sites60_k31.fa", 31, 0), ("sites60_k11.fa", 11, 0), ("sites_lower.fa.gz", 19, 0), ("sites200.fa", 32, 1), ("sites200.fa", 1, 1)):
+        p = subprocess.run([exe, os.path.join(G, "inputs", sites), str(k), str(dupes)] + reads, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, (sites, k, p.stderr.decode()[-2000:])
+        assert b"records=" in p.stdout
