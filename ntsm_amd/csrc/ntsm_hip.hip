@@ -527,6 +527,7 @@ struct ntsm_ctx {
 	uint64_t mask = 0;
 	/* device tables */
 	uint32_t *d_filter = nullptr, *d_slot_of = nullptr, *d_read_hits = nullptr;
+	uint64_t read_hits_cap = 0;
 	uint64_t *d_keys = nullptr;
 	unsigned long long *d_slot_counts = nullptr, *d_totals = nullptr, *d_vec = nullptr;
 	uint8_t *d_lut = nullptr;
@@ -770,54 +771,69 @@ int read_device_totals(ntsm_ctx *c, uint64_t out[2])
 int armed_batch(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t n_bytes,
 		const uint64_t *d_read_end, const uint64_t *h_read_end_or_null, uint64_t n_reads)
 {
-	uint64_t before[2];
-	HIPCHK(hipStreamSynchronize(st));
-	int rc = read_device_totals(c, before);
-	if (rc) return rc;
-	if (n_reads > c->cap_reads && c->d_read_hits) { (void) hipFree(c->d_read_hits); c->d_read_hits = nullptr; }
+	(void) n_bytes;
+	/* The batch is walked in chunks of kArmedChunkReads reads so that the work done is proportional to
+	 * what is consumed before the stop, not to the size of the batch. */
+	constexpr uint64_t CH = 1ull << 20;
+	const uint64_t n_chunks = (n_reads + CH - 1) / CH;
+	std::vector<uint64_t> bend(n_chunks);                 /* offset of the last terminator of every chunk */
+	if (h_read_end_or_null) {
+		for (uint64_t k = 0; k < n_chunks; ++k) bend[k] = h_read_end_or_null[std::min(n_reads, (k + 1) * CH) - 1];
+	} else {
+		if (n_chunks > 1)                                  /* one 8-byte element per CH reads: strided copy */
+			HIPCHK(hipMemcpy2D(bend.data(), sizeof(uint64_t), d_read_end + (CH - 1), CH * sizeof(uint64_t),
+					sizeof(uint64_t), n_chunks - 1, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(&bend[n_chunks - 1], d_read_end + (n_reads - 1), sizeof(uint64_t), hipMemcpyDeviceToHost));
+	}
+	const uint64_t hits_cap = std::min(n_reads, CH);
+	if (c->d_read_hits && c->read_hits_cap < hits_cap) { (void) hipFree(c->d_read_hits); c->d_read_hits = nullptr; }
 	if (!c->d_read_hits) {
-		const uint64_t cap = n_reads > c->cap_reads ? n_reads : c->cap_reads;
-		HIPCHK(hipMalloc(&c->d_read_hits, cap * sizeof(uint32_t)));
-		if (n_reads > c->cap_reads) c->cap_reads = n_reads;
+		HIPCHK(hipMalloc(&c->d_read_hits, hits_cap * sizeof(uint32_t)));
+		c->read_hits_cap = hits_cap;
 	}
-	HIPCHK(hipMemsetAsync(c->d_read_hits, 0, n_reads * sizeof(uint32_t), st));
-	rc = launch_count(c, st, d_bases, 0, n_bytes, d_read_end, n_reads, true, +1);
-	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(st));
-	uint64_t after[2];
-	rc = read_device_totals(c, after);
+	uint64_t run[2];
+	int rc = read_device_totals(c, run);
 	if (rc) return rc;
-	std::vector<uint64_t> re_local;
-	const uint64_t *re = h_read_end_or_null;
-	if (after[1] <= c->max_hits) {                        /* no crossing in this batch */
-		if (!re) {
-			uint64_t last = 0;
-			HIPCHK(hipMemcpy(&last, d_read_end + (n_reads - 1), sizeof last, hipMemcpyDeviceToHost));
-			c->total_bases += last + 1 - n_reads;
-		} else {
-			c->total_bases += re[n_reads - 1] + 1 - n_reads;
+	for (uint64_t k = 0; k < n_chunks; ++k) {
+		const uint64_t r0 = k * CH, r1 = std::min(n_reads, r0 + CH), nr = r1 - r0;
+		const uint64_t lo = k ? bend[k - 1] + 1 : 0, hi = bend[k] + 1;
+		HIPCHK(hipMemsetAsync(c->d_read_hits, 0, nr * sizeof(uint32_t), st));
+		rc = launch_count(c, st, d_bases, lo, hi, d_read_end + r0, nr, true, +1);
+		if (rc) return rc;
+		HIPCHK(hipStreamSynchronize(st));
+		uint64_t after[2];
+		rc = read_device_totals(c, after);
+		if (rc) return rc;
+		if (after[1] <= c->max_hits) {                    /* no crossing in this chunk */
+			c->total_bases += (hi - lo) - nr;
+			c->reads_consumed += nr;
+			run[1] = after[1];
+			continue;
 		}
-		c->reads_consumed += n_reads;
-		return NTSM_OK;
+		/* crossing: first read r* (strict '>') after which the cumulative hit count exceeds max_hits */
+		std::vector<uint32_t> hits(nr);
+		HIPCHK(hipMemcpy(hits.data(), c->d_read_hits, nr * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		std::vector<uint64_t> re_local;
+		const uint64_t *re = h_read_end_or_null ? h_read_end_or_null + r0 : nullptr;
+		if (!re) {
+			re_local.resize(nr);
+			HIPCHK(hipMemcpy(re_local.data(), d_read_end + r0, nr * sizeof(uint64_t), hipMemcpyDeviceToHost));
+			re = re_local.data();
+		}
+		uint64_t acc = run[1], rstar = nr - 1;
+		for (uint64_t r = 0; r < nr; ++r) {
+			acc += hits[r];
+			if (acc > c->max_hits) { rstar = r; break; }
+		}
+		rc = launch_count(c, st, d_bases, re[rstar] + 1, hi, nullptr, 0, false, -1);   /* take the reads after r* out again */
+		if (rc) return rc;
+		HIPCHK(hipStreamSynchronize(st));
+		c->total_bases += (re[rstar] + 1 - lo) - (rstar + 1);
+		c->reads_consumed += rstar + 1;
+		c->early_stop = true;
+		break;
 	}
-	std::vector<uint32_t> hits(n_reads);
-	HIPCHK(hipMemcpy(hits.data(), c->d_read_hits, n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	if (!re) {
-		re_local.resize(n_reads);
-		HIPCHK(hipMemcpy(re_local.data(), d_read_end, n_reads * sizeof(uint64_t), hipMemcpyDeviceToHost));
-		re = re_local.data();
-	}
-	uint64_t run = before[1], rstar = n_reads - 1;
-	for (uint64_t r = 0; r < n_reads; ++r) {
-		run += hits[r];
-		if (run > c->max_hits) { rstar = r; break; }
-	}
-	rc = launch_count(c, st, d_bases, re[rstar] + 1, n_bytes, nullptr, 0, false, -1);
-	if (rc) return rc;
-	HIPCHK(hipStreamSynchronize(st));
-	c->total_bases += re[rstar] + 1 - (rstar + 1);
-	c->reads_consumed += rstar + 1;
-	c->early_stop = true;
 	return NTSM_OK;
 }
 
@@ -990,7 +1006,6 @@ int ntsm_set_batch_capacity(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads)
 	}
 	c->cap_bytes = cap_bytes;
 	c->cap_reads = cap_reads;
-	if (c->d_read_hits) { (void) hipFree(c->d_read_hits); c->d_read_hits = nullptr; }
 	return NTSM_OK;
 }
 

@@ -376,3 +376,34 @@ def test_merge_counts_single_rank_roundtrip(nt, n10):
     ctx.submit(s.host_bytes(0, 10), s.read_end(10))      # new local work invalidates the merged view
     assert ctx.sync().reads_consumed == n + 10
     ctx.close()
+
+
+def test_early_stop_across_chunks(nt, n10):
+    """The armed path walks big batches in chunks of 2^20 reads: a threshold that trips in the second chunk of a
+    resident 1.3 M-read batch stops at the oracle's read, with the oracle's totals and counts."""
+    import torch
+    s, sites, path = n10
+    n, probe = 1_300_000, 1_150_000
+    dev = torch.device("cuda:0")
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d_bases = torch.empty(n * s.stride, dtype=torch.uint8, device=dev)
+    s.device_fill(d_win.data_ptr(), 0, n, d_bases.data_ptr())
+    d_ends = torch.from_numpy(s.read_end(n).view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    ctx = nt.Context(sites.keys)
+    ctx.count_resident(d_bases.data_ptr(), probe * s.stride, 0, probe)
+    thr = ctx.sync().total_hits                             # hits of the first 1.15 M reads (unarmed path, parity-tested)
+    ctx.close()
+    cov = 2.0 * (thr + 0.5) / len(sites.keys)
+    fp = OracleFP(path, cov=cov)
+    assert fp.max_hits == thr
+    bases = s.host_bytes(0, n)
+    fp.process_flat(bases, s.read_end(n))
+    assert fp.early_term and probe < fp.reads_processed < n
+    ctx = nt.Context(sites.keys, max_hits=thr)
+    ctx.count_resident(d_bases.data_ptr(), d_bases.numel(), d_ends.data_ptr(), n)
+    t = ctx.sync()
+    assert t.early_stop == 1 and t.reads_consumed == fp.reads_processed
+    assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases)
+    assert np.array_equal(ctx.counts(), fp.kmers()[2])
+    ctx.close()
