@@ -54,14 +54,20 @@ NTSM_DHD uint32_t ntsm_mmer_hash(uint32_t cm)
 	return (uint32_t) ((uint64_t) cm * 0x9E3779u);
 #endif
 }
-/* filter block of a minimizer value: 24x24-bit multiply (full rate on CDNA) of the low 24 bits of the
- * order hash -- a bijective image of the 12-mer that the min-selection leaves unbiased */
-NTSM_DHD uint32_t ntsm_block_of(uint32_t mz, uint32_t blk_shift)
+/* BYTE offset of the filter block of a minimizer value.  The filter has n_blocks = mult * 2^e blocks with
+ * mult in {1, 3} (3: sizes like 3 MiB that leave room in the 4 MiB per-XCD L2 for the read stream), so the
+ * index is a multiply-shift range reduction: h = 24x24-bit multiply (full rate on CDNA) of the low 24 bits of
+ * the order hash -- a bijective image of the 12-mer that the min-selection leaves unbiased --, q = its top
+ * (e + slack) bits, index = (q * mult) >> slack. */
+struct NtsmBlockMap { uint32_t qshift, mult, sshift; };      /* q = h >> qshift; off = ((q * mult) >> sshift) & ~7 */
+NTSM_DHD uint32_t ntsm_block_off(uint32_t mz, NtsmBlockMap m)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return (uint32_t) __umul24(mz, 0xC2B2AFu) >> blk_shift;    /* __umul24 is declared int in HIP: shift unsigned */
+	const uint32_t h = (uint32_t) __umul24(mz, 0xC2B2AFu);      /* __umul24 is declared int in HIP */
+	return ((uint32_t) __umul24(h >> m.qshift, m.mult) >> m.sshift) & ~7u;
 #else
-	return (uint32_t) ((uint64_t) (mz & 0xFFFFFFu) * 0xC2B2AFu) >> blk_shift;
+	const uint32_t h = (uint32_t) ((uint64_t) (mz & 0xFFFFFFu) * 0xC2B2AFu);
+	return ((uint32_t) ((uint64_t) (h >> m.qshift) * m.mult) >> m.sshift) & ~7u;
 #endif
 }
 /* Two filter bits per site k-mer, one in each 32-bit half of the block: bit (u >> 27) of the low word
@@ -96,7 +102,8 @@ struct NtsmCountParams {
 	const uint8_t *lut;                /* 256-byte base table, vendor/KseqHashIterator.hpp:114-127 */
 	const uint2 *lut64;                /* fast path: per byte { code, (3 - code) | invalid << 31 } */
 	const unsigned long long *blocks;  /* k = 19 fast path: minimizer-addressed 64-bit filter blocks */
-	uint32_t blk_shift;                /* block index = (mz * C) >> blk_shift */
+	NtsmBlockMap blk_map;              /* minimizer -> filter block offset */
+	uint32_t blk_bytes;                /* size of the filter in bytes (buffer descriptor range) */
 };
 
 #endif

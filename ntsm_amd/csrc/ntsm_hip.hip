@@ -241,10 +241,11 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 	const int lane = t & 63;
 	uint16_t *queue = queue_all[t >> 6];
 	lut64[t] = p.lut64[t];
-	const uint32_t bshift = p.bshift, blk_shift = p.blk_shift;
+	const uint32_t bshift = p.bshift;
+	const NtsmBlockMap blk_map = p.blk_map;
 	/* buffer resource over the filter blocks: one instruction per load, 32-bit byte offset */
 	const __amdgpu_buffer_rsrc_t blk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-			const_cast<unsigned long long *>(p.blocks), 0, (int) (8u << (32 - blk_shift)), 0x00020000);
+			const_cast<unsigned long long *>(p.blocks), 0, (int) p.blk_bytes, 0x00020000);
 	uint32_t nk = 0, nh = 0;
 
 	for (unsigned long long ti = blockIdx.x; ti < p.n_tiles; ti += gridDim.x) {
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				 * position's or the previous window was invalid (then no block is cached for it). */
 				B.ok[j] = (inv & 0x7FFFFu) == 0;
 				B.nd[j] = B.ok[j] & ((mz != mz_prev) | !ok_prev);
-				idx[j] = B.nd[j] ? (ntsm_block_of(mz, blk_shift) << 3) : 0xFFFFFFFFu;   /* out of range: returns 0, no memory request */
+				idx[j] = B.nd[j] ? ntsm_block_off(mz, blk_map) : 0xFFFFFFFFu;   /* out of range: returns 0, no memory request */
 				mz_prev = mz;
 				ok_prev = B.ok[j];
 				nk += B.ok[j] ? 1u : 0u;
@@ -535,7 +536,8 @@ struct ntsm_ctx {
 	uint32_t filter_log2 = 0, bucket_log2 = 0;
 	uint64_t n_slots = 0;
 	unsigned long long *d_blocks = nullptr;    /* k = 19 fast path: minimizer-addressed filter blocks */
-	uint32_t block_log2 = 0;                   /* log2(number of 64-bit blocks) */
+	uint64_t n_blocks = 0;                     /* number of 64-bit filter blocks: mult * 2^e, mult in {1, 3} */
+	NtsmBlockMap blk_map = { 0, 1, 0 };
 	int kernel_variant = 0;                    /* 0 auto (fast path when k == 19), 1 generic */
 	std::vector<uint64_t> canon;               /* host copy of the canonical keys */
 	std::vector<uint32_t> slot_of;
@@ -623,15 +625,29 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		const uint32_t bit = ntsm_h1(ntsm_fold(c->canon[i])) >> fshift;
 		filter[bit >> 5] |= 1u << (bit & 31);
 	}
-	/* k = 19: minimizer-addressed blocked filter (>= 16 bits per key: 4 MiB for the human set) */
+	/* k = 19: minimizer-addressed blocked filter.  Size = smallest of {2^e, 3 * 2^(e-2)} blocks with at least
+	 * 12 bits per key: 3 MiB for the 1.54 M-key human set -- it must leave room in the 4 MiB per-XCD L2 for the
+	 * read stream and the bucket lines, a full 4 MiB filter misses L2 on 18 % of its reads. */
 	std::vector<unsigned long long> blocks;
 	if (c->k == NTSM_FAST_K) {
-		uint32_t bits_log2 = 12;
-		while (bits_log2 < 30 && (1ull << bits_log2) < 16ull * n) ++bits_log2;
-		if (filter_log2_req >= 10 && filter_log2_req <= 30) bits_log2 = (uint32_t) filter_log2_req;
-		c->block_log2 = bits_log2 - 6;
-		blocks.assign(1ull << c->block_log2, 0ull);
-		const uint32_t blk_shift = 32 - c->block_log2;
+		uint32_t e = 6, mult = 1;
+		if (filter_log2_req >= 100 && filter_log2_req <= 130) {          /* 100 + v: 3 * 2^v bits */
+			mult = 3; e = (uint32_t) (filter_log2_req - 100) - 6;
+		} else if (filter_log2_req >= 10 && filter_log2_req <= 30) {
+			e = (uint32_t) filter_log2_req - 6;
+		} else {
+			const uint64_t want = (12ull * n + 63) / 64;                  /* blocks */
+			while ((1ull << e) < want && e < 21) ++e;
+			if (e > 8 && (3ull << (e - 2)) >= want) { mult = 3; e -= 2; }   /* 0.75 * 2^e is enough */
+		}
+		if (e > 21) e = 21;
+		if (e < 4) e = 4;
+		const uint32_t slack = 24 - e < 6 ? 24 - e : 6;                   /* e + slack <= 24 (mul24 operand), slack >= 3 */
+		c->n_blocks = (uint64_t) mult << e;
+		c->blk_map.qshift = 32 - (e + slack);
+		c->blk_map.mult = mult;
+		c->blk_map.sshift = slack - 3;
+		blocks.assign(c->n_blocks, 0ull);
 		for (uint32_t i = 0; i < n; ++i) {
 			const uint64_t x = c->canon[i];
 			uint64_t rc = 0;
@@ -644,8 +660,9 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 				mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
 			}
 			const uint32_t kb = ntsm_kmer_bits((uint32_t) (x >> 6), (uint32_t) (rc >> 6));
-			blocks[ntsm_block_of(mz, blk_shift)] |= (1ull << NTSM_KBIT_LO(kb)) | (1ull << (32u + NTSM_KBIT_HI(kb)));
+			blocks[ntsm_block_off(mz, c->blk_map) >> 3] |= (1ull << NTSM_KBIT_LO(kb)) | (1ull << (32u + NTSM_KBIT_HI(kb)));
 		}
+		if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0ull);   /* ablation only: wrong counts */
 	}
 	/* upload */
 	if (c->d_blocks) (void) hipFree(c->d_blocks);
@@ -724,8 +741,9 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.lut = c->d_lut;
 	p.lut64 = c->d_lut64;
 	p.blocks = c->d_blocks;
-	p.blk_shift = 32 - c->block_log2;
-	const bool fast = c->k == NTSM_FAST_K && c->d_blocks && c->kernel_variant != 1 && c->block_log2 >= 1;
+	p.blk_map = c->blk_map;
+	p.blk_bytes = (uint32_t) (c->n_blocks * 8);
+	const bool fast = c->k == NTSM_FAST_K && c->d_blocks && c->kernel_variant != 1;
 	uint64_t grid = c->grid_blocks > 0 ? (uint64_t) c->grid_blocks : (uint64_t) c->n_cu * 4;
 	if (grid > p.n_tiles) grid = p.n_tiles;
 	int ev = -1;

@@ -1,5 +1,5 @@
 cd /tmp; export TMPDIR=/tmp
-for f in 24 25; do
+for f in 0 123 25 122; do
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d /root/repo/gpurun_out/tcc_f$f -- python3 /root/repo/bench.py --reads 1e8 --steps 2 --warmup 1 --no-cpu-baseline --filter-log2 $f > /root/repo/gpurun_out/tcc_f$f.log 2>&1
   python3 - $f <<'PY'
 import csv,glob,sys,collections,json
