@@ -103,6 +103,9 @@ struct NtsmCountParams {
 	const uint2 *lut64;                /* fast path: per byte { code, (3 - code) | invalid << 31 } */
 	const unsigned long long *blocks;  /* k = 19 fast path: minimizer-addressed 64-bit filter blocks */
 	NtsmBlockMap blk_map;              /* minimizer -> filter block offset */
+	const uint32_t *prefilter;         /* fast path, drain only: plain 2-bit Bloom over canonical codes (L2 resident) */
+	uint32_t pf_shift;                 /* word index = h1(fold) >> pf_shift; bits = h2(fold) & 31, (h2 >> 5) & 31 */
+	uint32_t debug;                    /* ablation switches (NTSM_DEBUG_KERNEL): 1 = drain discards its queue, 2 = drain stops after the k-mer rebuild */
 	uint32_t blk_bytes;                /* size of the filter in bytes (buffer descriptor range) */
 };
 

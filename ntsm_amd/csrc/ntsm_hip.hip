@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 #define NTSM_FAST_PIPELINE 0
 #endif
 constexpr int kFastC = 128;
-constexpr int kQueueCap = 64 + 8 * 64;                 /* < 64 left over + one 8-position burst */
+constexpr int kQueueCap = 128;                         /* < 64 left over + one position's burst of <= 64 */
 
 /* LDS image of a tile: row r (128 B) = stream bytes of thread r-1 (row 0 = the 32 bytes in front of
  * the tile, in its last two slots).  16-byte slot s of row r sits at physical slot s ^ ((r >> 1) & 7):
@@ -236,10 +236,12 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 	constexpr int C = kFastC, VPT = C / 16, NB = C / 8;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * C];
 	__shared__ uint2 lut64[256];
-	__shared__ uint16_t queue_all[kThreads / 64][kQueueCap + 64 * NTSM_FAST_BRANCHLESS_PUSH];
+	__shared__ uint2 queue_all[kThreads / 64][kQueueCap];          /* positives: { first-16 forward word, last-16 reverse word } */
+	__shared__ uint16_t qpos_all[PER_READ ? kThreads / 64 : 1][PER_READ ? kQueueCap : 1];   /* -m mode: their tile offsets */
 	const int t = threadIdx.x;
 	const int lane = t & 63;
-	uint16_t *queue = queue_all[t >> 6];
+	uint2 *queue = queue_all[t >> 6];
+	uint16_t *qpos = qpos_all[PER_READ ? (t >> 6) : 0];
 	lut64[t] = p.lut64[t];
 	const uint32_t bshift = p.bshift;
 	const NtsmBlockMap blk_map = p.blk_map;
@@ -303,53 +305,44 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			while (qn >= 64 || (all && qn > 0)) {
 				const uint32_t n = qn < 64 ? qn : 64;
 				qn -= n;
-				if ((uint32_t) lane < n) {
-					const int off = queue[qn + lane];            /* tile offset of the window's last base */
-					/* the 19 bytes off-18 .. off: six aligned dwords (a dword never straddles a swizzled
-					 * 16-byte slot), then a byte funnel shift */
-					const int x0 = off - 18 + C;                 /* +C: row 0 is the halo row */
-					uint32_t d6[6], by[5];
-#pragma unroll
-					for (int q = 0; q < 6; ++q) {
-						int xd = (x0 & ~3) + 4 * q;
-						xd = xd > (kThreads + 1) * C - 4 ? (kThreads + 1) * C - 4 : xd;
-						d6[q] = *reinterpret_cast<const uint32_t *>(tile + ntsm_tile_addr(xd >> 7, xd & (C - 1)));
-					}
-#pragma unroll
-					for (int k = 0; k < 5; ++k) by[k] = __builtin_amdgcn_alignbyte(d6[k + 1], d6[k], (uint32_t) (x0 & 3));
-					/* pack the forward code (first base on top): 3 bases in the high word, 16 in the low */
-					uint32_t cc[19];
-#pragma unroll
-					for (int k = 0; k < 19; ++k) cc[k] = lut64[(by[k >> 2] >> ((k & 3) * 8)) & 0xFFu].x;
-					uint32_t a_hi = (cc[0] << 4) | (cc[1] << 2) | cc[2], a_lo = 0;
-#pragma unroll
-					for (int k = 3; k < 19; ++k) a_lo = (a_lo << 2) | cc[k];
-					/* reverse complement: reverse the 64 bits, swap the bits of each pair back, complement, align */
-					uint32_t r_hi = __builtin_bitreverse32(a_lo), r_lo = __builtin_bitreverse32(a_hi);
-					r_hi = ((r_hi & 0x55555555u) << 1) | ((r_hi >> 1) & 0x55555555u);
-					r_lo = ((r_lo & 0x55555555u) << 1) | ((r_lo >> 1) & 0x55555555u);
-					const unsigned long long rv = (~(((unsigned long long) r_hi << 32) | r_lo)) >> 26;
-					const uint32_t b_lo = (uint32_t) rv, b_hi = (uint32_t) (rv >> 32);
+				if ((uint32_t) lane < n && !(p.debug & 1u)) {
+					/* rebuild both 38-bit strands from the two 16-base words: the forward code is the first 16
+					 * bases followed by the last 3 (complement-reversed top 3 groups of the reverse word), the
+					 * reverse-complement code is the reverse word followed by the complement-reversed first 3 */
+					const uint2 q = queue[qn + lane];
+					const uint32_t f3 = q.x, r = q.y;
+					const uint32_t tf = f3 >> 26, tr = r >> 26;
+					const uint32_t l3 = 63u ^ (((tr & 3u) << 4) | (tr & 0xCu) | (tr >> 4));
+					const uint32_t r3 = 63u ^ (((tf & 3u) << 4) | (tf & 0xCu) | (tf >> 4));
+					const uint32_t a_hi = tf, a_lo = (f3 << 6) | l3;
+					const uint32_t b_hi = tr, b_lo = (r << 6) | r3;
 					const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
 					const uint32_t klo = lt ? a_lo : b_lo, khi = lt ? a_hi : b_hi;
 					const uint32_t fo = ntsm_fold(((unsigned long long) khi << 32) | klo);
-					const unsigned long long b1 = 2ull * (ntsm_h1(fo) >> bshift);
-					const uint4 ba = *reinterpret_cast<const uint4 *>(p.keys + b1);
+					const uint32_t g1 = ntsm_h1(fo), g2 = ntsm_h2(fo);
+					/* second-level filter (L2 resident, exact canonical code, well-mixed hash): most first-level
+					 * false positives stop here instead of costing an Infinity-Cache access to the key table */
+					const uint32_t pw = p.prefilter[g1 >> p.pf_shift];
 					long long slot = -1;
-					if (ba.x == klo && ba.y == khi) slot = (long long) b1;
-					else if (ba.z == klo && ba.w == khi) slot = (long long) b1 + 1;
-					else if ((ba.x & ba.y) != 0xFFFFFFFFu && (ba.z & ba.w) != 0xFFFFFFFFu) {
-						/* bucket 1 full and no match: the key can only be in bucket 2 */
-						const unsigned long long b2 = 2ull * (ntsm_h2(fo) >> bshift);
-						const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + b2);
-						if (bb.x == klo && bb.y == khi) slot = (long long) b2;
-						else if (bb.z == klo && bb.w == khi) slot = (long long) b2 + 1;
+					if (((pw >> (g2 & 31u)) & (pw >> ((g2 >> 5) & 31u)) & 1u) && !(p.debug & 2u)) {
+						const unsigned long long b1 = 2ull * (g1 >> bshift);
+						const uint4 ba = *reinterpret_cast<const uint4 *>(p.keys + b1);
+						if (ba.x == klo && ba.y == khi) slot = (long long) b1;
+						else if (ba.z == klo && ba.w == khi) slot = (long long) b1 + 1;
+						else if ((ba.x & ba.y) != 0xFFFFFFFFu && (ba.z & ba.w) != 0xFFFFFFFFu) {
+							/* bucket 1 full and no match: the key can only be in bucket 2 */
+							const unsigned long long b2 = 2ull * (g2 >> bshift);
+							const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + b2);
+							if (bb.x == klo && bb.y == khi) slot = (long long) b2;
+							else if (bb.z == klo && bb.w == khi) slot = (long long) b2 + 1;
+						}
 					}
 					if (slot >= 0) {
-						__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (!(p.debug & 4u))
+							__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						++nh;
 						if (PER_READ)
-							atomicAdd(p.read_hits + ntsm_read_of(p, (unsigned long long) (ts + off)), 1u);
+							atomicAdd(p.read_hits + ntsm_read_of(p, (unsigned long long) (ts + qpos[qn + lane])), 1u);
 					}
 				}
 			}
@@ -358,7 +351,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 		/* Phase A of one 8-position block: roll, 12-mer order hashes, sliding minimum, k-mer bit hash;
 		 * decides per position whether the minimizer changed (nd) and issues the 8 filter-block loads
 		 * (lanes that keep their block all read block 0: one request per wave instruction). */
-		struct BlockState { uint32_t kb[8]; bool ok[8], nd[8]; uint2 bl[8]; };
+		struct BlockState { uint32_t f3[8], r[8]; bool ok[8], nd[8]; uint2 bl[8]; };
 		auto phase_a = [&](const uint2 v, BlockState &B) {
 			const uint32_t w[2] = { v.x, v.y };
 			uint2 e8[8];
@@ -372,7 +365,8 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				gg[j] = NTSM_MMER_G();
 				pm = min(pm, gg[j]);
 				const uint32_t mz = j < 7 ? min(sprev[j + 1], pm) : pm;
-				B.kb[j] = ntsm_kmer_bits(j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)), R);
+				B.f3[j] = j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2));
+				B.r[j] = R;
 				/* plain & / | (no short circuit): keeps this straight-line code instead of exec-masked regions.
 				 * A lane (re)loads when its window is valid and either the minimizer differs from the previous
 				 * position's or the previous window was invalid (then no block is cached for it). */
@@ -399,24 +393,19 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			for (int j = 0; j < 8; ++j) {
 				cur_lo = B.nd[j] ? B.bl[j].x : cur_lo;
 				cur_hi = B.nd[j] ? B.bl[j].y : cur_hi;
-				const bool pass = B.ok[j] & (((cur_lo >> NTSM_KBIT_LO(B.kb[j])) & (cur_hi >> NTSM_KBIT_HI(B.kb[j])) & 1u) != 0);
+				const uint32_t kb = ntsm_kmer_bits(B.f3[j], B.r[j]);
+				const bool pass = B.ok[j] & (((cur_lo >> NTSM_KBIT_LO(kb)) & (cur_hi >> NTSM_KBIT_HI(kb)) & 1u) != 0);
 				const unsigned long long m = __ballot(pass);
-#if NTSM_FAST_BRANCHLESS_PUSH
-				/* every lane stores: positives at their compacted slot, the rest into a per-lane trash slot */
-				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-				queue[pass ? qn + rank : (uint32_t) (kQueueCap + lane)] = (uint16_t) (pos0 + j);
-				qn += (uint32_t) __popcll(m);
-#else
 				if (m) {
 					if (pass) {
 						const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-						queue[at] = (uint16_t) (pos0 + j);
+						queue[at] = make_uint2(B.f3[j], B.r[j]);
+						if (PER_READ) qpos[at] = (uint16_t) (pos0 + j);
 					}
 					qn += (uint32_t) __popcll(m);
+					if (qn >= 64) drain(false);
 				}
-#endif
 			}
-			if (qn >= 64) drain(false);
 		};
 
 #if NTSM_FAST_PIPELINE
@@ -537,6 +526,8 @@ struct ntsm_ctx {
 	uint64_t n_slots = 0;
 	unsigned long long *d_blocks = nullptr;    /* k = 19 fast path: minimizer-addressed filter blocks */
 	uint64_t n_blocks = 0;                     /* number of 64-bit filter blocks: mult * 2^e, mult in {1, 3} */
+	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
+	uint32_t prefilter_log2 = 0;               /* log2(bits) */
 	NtsmBlockMap blk_map = { 0, 1, 0 };
 	int kernel_variant = 0;                    /* 0 auto (fast path when k == 19), 1 generic */
 	std::vector<uint64_t> canon;               /* host copy of the canonical keys */
@@ -664,9 +655,33 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		}
 		if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0ull);   /* ablation only: wrong counts */
 	}
+	/* second-level filter of the fast path: plain Bloom, 2 bits per key in one 32-bit word, >= 5 bits per key
+	 * (1 MiB for the human set: with the 3 MiB first level it still fits the 4 MiB per-XCD L2) */
+	std::vector<uint32_t> prefilter;
+	if (c->k == NTSM_FAST_K) {
+		uint32_t pl = 10;
+		while (pl < 28 && (1ull << pl) < 5ull * n) ++pl;
+		if (const char *ev = getenv("NTSM_PREFILTER_LOG2")) pl = (uint32_t) atoi(ev);
+		if (pl < 10) pl = 10;
+		if (pl > 30) pl = 30;
+		c->prefilter_log2 = pl;
+		prefilter.assign((1ull << pl) / 32, 0u);
+		const uint32_t pshift = 32 - (pl - 5);
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t f = ntsm_fold(c->canon[i]), g1 = ntsm_h1(f), g2 = ntsm_h2(f);
+			prefilter[g1 >> pshift] |= (1u << (g2 & 31u)) | (1u << ((g2 >> 5) & 31u));
+		}
+		if (getenv("NTSM_PREFILTER_OFF")) std::fill(prefilter.begin(), prefilter.end(), 0xFFFFFFFFu);   /* ablation: everything passes */
+	}
 	/* upload */
 	if (c->d_blocks) (void) hipFree(c->d_blocks);
+	if (c->d_prefilter) (void) hipFree(c->d_prefilter);
 	c->d_blocks = nullptr;
+	c->d_prefilter = nullptr;
+	if (!prefilter.empty()) {
+		HIPCHK(hipMalloc(&c->d_prefilter, prefilter.size() * sizeof(uint32_t)));
+		HIPCHK(hipMemcpy(c->d_prefilter, prefilter.data(), prefilter.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
 	if (!blocks.empty()) {
 		HIPCHK(hipMalloc(&c->d_blocks, blocks.size() * sizeof(unsigned long long)));
 		HIPCHK(hipMemcpy(c->d_blocks, blocks.data(), blocks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
@@ -742,6 +757,9 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.lut64 = c->d_lut64;
 	p.blocks = c->d_blocks;
 	p.blk_map = c->blk_map;
+	p.prefilter = c->d_prefilter;
+	if (const char *dv = getenv("NTSM_DEBUG_KERNEL")) p.debug = (uint32_t) atoi(dv);
+	p.pf_shift = 32 - (c->prefilter_log2 - 5);
 	p.blk_bytes = (uint32_t) (c->n_blocks * 8);
 	const bool fast = c->k == NTSM_FAST_K && c->d_blocks && c->kernel_variant != 1;
 	uint64_t grid = c->grid_blocks > 0 ? (uint64_t) c->grid_blocks : (uint64_t) c->n_cu * 4;
@@ -1008,7 +1026,7 @@ void ntsm_destroy(ntsm_ctx *c)
 		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
 		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
 	}
-	void *ptrs[] = { c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_counts, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
+	void *ptrs[] = { c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_counts, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
 	for (void *p : ptrs) if (p) (void) hipFree(p);
 	delete c;
 }
