@@ -300,12 +300,52 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 		uint32_t mz_prev = 0, cur_lo = 0, cur_hi = 0;
 		bool ok_prev = false;                               /* nothing cached at the start of a chunk */
 
-		/* drain: look up queued positives, 64 at a time (or the remainder when `all`) */
-		auto drain = [&](bool all) {
-			while (qn >= 64 || (all && qn > 0)) {
+		/* Drain: look up queued positives 64 at a time, as a three-stage pipeline spread over consecutive
+		 * calls so that no load is consumed in the call that issued it (the wave goes back to the main
+		 * loop while its second-level-filter word, then its key bucket, are on their way):
+		 *   stage 1  pop 64 entries, rebuild the canonical code, issue the second-level filter load
+		 *   stage 2  (next call) test the filter word, issue the bucket load for the survivors
+		 *   stage 3  (call after) compare the bucket, rare second bucket inline, bump the counter
+		 * `flush` pushes everything through at the end of a tile. */
+		uint32_t s1_klo = 0, s1_khi = 0, s1_g1 = 0, s1_g2 = 0, s1_pw = 0, s1_pos = 0;
+		uint32_t s2_klo = 0, s2_khi = 0, s2_g2 = 0, s2_pos = 0;
+		unsigned long long s2_b1 = 0;
+		uint4 s2_ba = make_uint4(0, 0, 0, 0);
+		bool s1_v = false, s2_v = false;
+		auto drain_step = [&](bool take) {
+			/* stage 3 */
+			if (s2_v) {
+				long long slot = -1;
+				if (s2_ba.x == s2_klo && s2_ba.y == s2_khi) slot = (long long) s2_b1;
+				else if (s2_ba.z == s2_klo && s2_ba.w == s2_khi) slot = (long long) s2_b1 + 1;
+				else if ((s2_ba.x & s2_ba.y) != 0xFFFFFFFFu && (s2_ba.z & s2_ba.w) != 0xFFFFFFFFu) {
+					/* bucket 1 full and no match: the key can only be in bucket 2 */
+					const unsigned long long b2 = 2ull * (s2_g2 >> bshift);
+					const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + b2);
+					if (bb.x == s2_klo && bb.y == s2_khi) slot = (long long) b2;
+					else if (bb.z == s2_klo && bb.w == s2_khi) slot = (long long) b2 + 1;
+				}
+				if (slot >= 0) {
+					if (!(p.debug & 4u))
+						__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					++nh;
+					if (PER_READ) atomicAdd(p.read_hits + ntsm_read_of(p, (unsigned long long) (ts + (long long) s2_pos)), 1u);
+				}
+			}
+			/* stage 2 */
+			s2_v = s1_v && (((s1_pw >> (s1_g2 & 31u)) & (s1_pw >> ((s1_g2 >> 5) & 31u)) & 1u) != 0) && !(p.debug & 2u);
+			if (s2_v) {
+				s2_klo = s1_klo; s2_khi = s1_khi; s2_g2 = s1_g2; s2_pos = s1_pos;
+				s2_b1 = 2ull * (s1_g1 >> bshift);
+				s2_ba = *reinterpret_cast<const uint4 *>(p.keys + s2_b1);
+			}
+			/* stage 1 */
+			s1_v = false;
+			if (take) {
 				const uint32_t n = qn < 64 ? qn : 64;
 				qn -= n;
-				if ((uint32_t) lane < n && !(p.debug & 1u)) {
+				s1_v = (uint32_t) lane < n && !(p.debug & 1u);
+				if (s1_v) {
 					/* rebuild both 38-bit strands from the two 16-base words: the forward code is the first 16
 					 * bases followed by the last 3 (complement-reversed top 3 groups of the reverse word), the
 					 * reverse-complement code is the reverse word followed by the complement-reversed first 3 */
@@ -317,35 +357,24 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 					const uint32_t a_hi = tf, a_lo = (f3 << 6) | l3;
 					const uint32_t b_hi = tr, b_lo = (r << 6) | r3;
 					const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
-					const uint32_t klo = lt ? a_lo : b_lo, khi = lt ? a_hi : b_hi;
-					const uint32_t fo = ntsm_fold(((unsigned long long) khi << 32) | klo);
-					const uint32_t g1 = ntsm_h1(fo), g2 = ntsm_h2(fo);
+					s1_klo = lt ? a_lo : b_lo;
+					s1_khi = lt ? a_hi : b_hi;
+					const uint32_t fo = ntsm_fold(((unsigned long long) s1_khi << 32) | s1_klo);
+					s1_g1 = ntsm_h1(fo);
+					s1_g2 = ntsm_h2(fo);
+					if (PER_READ) s1_pos = qpos[qn + lane];
 					/* second-level filter (L2 resident, exact canonical code, well-mixed hash): most first-level
 					 * false positives stop here instead of costing an Infinity-Cache access to the key table */
-					const uint32_t pw = p.prefilter[g1 >> p.pf_shift];
-					long long slot = -1;
-					if (((pw >> (g2 & 31u)) & (pw >> ((g2 >> 5) & 31u)) & 1u) && !(p.debug & 2u)) {
-						const unsigned long long b1 = 2ull * (g1 >> bshift);
-						const uint4 ba = *reinterpret_cast<const uint4 *>(p.keys + b1);
-						if (ba.x == klo && ba.y == khi) slot = (long long) b1;
-						else if (ba.z == klo && ba.w == khi) slot = (long long) b1 + 1;
-						else if ((ba.x & ba.y) != 0xFFFFFFFFu && (ba.z & ba.w) != 0xFFFFFFFFu) {
-							/* bucket 1 full and no match: the key can only be in bucket 2 */
-							const unsigned long long b2 = 2ull * (g2 >> bshift);
-							const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + b2);
-							if (bb.x == klo && bb.y == khi) slot = (long long) b2;
-							else if (bb.z == klo && bb.w == khi) slot = (long long) b2 + 1;
-						}
-					}
-					if (slot >= 0) {
-						if (!(p.debug & 4u))
-							__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						++nh;
-						if (PER_READ)
-							atomicAdd(p.read_hits + ntsm_read_of(p, (unsigned long long) (ts + qpos[qn + lane])), 1u);
-					}
+					s1_pw = p.prefilter[s1_g1 >> p.pf_shift];
 				}
 			}
+		};
+		auto drain = [&](bool all) {
+			if (!all) { drain_step(true); return; }
+			while (qn > 0) drain_step(true);
+			drain_step(false);                                 /* stage 1 -> 2 */
+			drain_step(false);                                 /* stage 2 -> 3 */
+			drain_step(false);                                 /* stage 3 */
 		};
 
 		/* Phase A of one 8-position block: roll, 12-mer order hashes, sliding minimum, k-mer bit hash;
