@@ -42,8 +42,11 @@ NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC
  * by a strand-symmetric hash of (fw, rc).  All functions below are shared by the host builder and
  * the kernel so that both sides agree bit for bit. */
 #define NTSM_FAST_K 19
-#define NTSM_FAST_M 12
+#ifndef NTSM_FAST_M
+#define NTSM_FAST_M 12                 /* minimizer length: 12 (window of 8 m-mers) or 11 (window of 9) */
+#endif
 #define NTSM_FAST_W (NTSM_FAST_K - NTSM_FAST_M + 1)
+#define NTSM_MMER_MASK ((1u << (2 * NTSM_FAST_M)) - 1u)
 
 /* order hash of a canonical 12-mer (24 bits): injective scramble, compared as an integer */
 NTSM_DHD uint32_t ntsm_mmer_hash(uint32_t cm)

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			R = __builtin_amdgcn_alignbit((e_).y, R, 2);                                  \
 			inv = __builtin_amdgcn_alignbit(inv, (e_).y, 31);                             \
 		}
-#define NTSM_MMER_G() ntsm_mmer_hash(min(F & 0xFFFFFFu, R >> 8))
+#define NTSM_MMER_G() ntsm_mmer_hash(min(F & NTSM_MMER_MASK, R >> (32 - 2 * NTSM_FAST_M)))
 		{   /* warm-up: the 18 bytes in front of the chunk; 12-mer hashes of positions -7..-1 */
 			const uint4 v0 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 32));
 			const uint4 v1 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 16));
@@ -290,12 +290,12 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				const uint2 e = lut64[(w[i >> 2] >> ((i & 3) * 8)) & 0xFFu];
 				NTSM_STEP(e)
 				fh[i] = F;
-				if (i >= 25) gw[i - 24] = NTSM_MMER_G();     /* i = 25..31 -> block index 1..7 */
+				if (i >= 24 + (9 - NTSM_FAST_W)) gw[i - 24] = NTSM_MMER_G();   /* the last W-1 positions of the previous 8-block */
 			}
 			fc0 = fh[29]; fc1 = fh[30]; fc2 = fh[31];
 			sprev[7] = gw[7];
 #pragma unroll
-			for (int i = 6; i >= 1; --i) sprev[i] = min(gw[i], sprev[i + 1]);
+			for (int i = 6; i >= 9 - NTSM_FAST_W; --i) sprev[i] = min(gw[i], sprev[i + 1]);
 		}
 		uint32_t mz_prev = 0, cur_lo = 0, cur_hi = 0;
 		bool ok_prev = false;                               /* nothing cached at the start of a chunk */
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				fh[j] = F;
 				gg[j] = NTSM_MMER_G();
 				pm = min(pm, gg[j]);
-				const uint32_t mz = j < 7 ? min(sprev[j + 1], pm) : pm;
+				const uint32_t mz = j + 9 - NTSM_FAST_W <= 7 ? min(sprev[j + 9 - NTSM_FAST_W], pm) : pm;
 				B.f3[j] = j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2));
 				B.r[j] = R;
 				/* plain & / | (no short circuit): keeps this straight-line code instead of exec-masked regions.
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			fc0 = fh[5]; fc1 = fh[6]; fc2 = fh[7];
 			sprev[7] = gg[7];
 #pragma unroll
-			for (int j = 6; j >= 1; --j) sprev[j] = min(gg[j], sprev[j + 1]);
+			for (int j = 6; j >= 9 - NTSM_FAST_W; --j) sprev[j] = min(gg[j], sprev[j + 1]);
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {                      /* buffer loads: 32-bit byte offset, range-checked by the descriptor */
 				const u32x2 bv = __builtin_amdgcn_raw_buffer_load_b64(blk_rsrc, (int) idx[j], 0, 0);
@@ -674,7 +674,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			for (int b = 0; b < NTSM_FAST_K; ++b) rc |= (3ull - ((x >> (2 * b)) & 3ull)) << (2 * (NTSM_FAST_K - 1 - b));
 			uint32_t mz = 0xFFFFFFFFu;
 			for (int j = 0; j < NTSM_FAST_W; ++j) {
-				const uint32_t sub = (uint32_t) (x >> (2 * j)) & 0xFFFFFFu;
+				const uint32_t sub = (uint32_t) (x >> (2 * j)) & NTSM_MMER_MASK;
 				uint32_t rsub = 0;
 				for (int b = 0; b < NTSM_FAST_M; ++b) rsub |= (3u - ((sub >> (2 * b)) & 3u)) << (2 * (NTSM_FAST_M - 1 - b));
 				mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
