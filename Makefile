@@ -25,7 +25,7 @@ ntsm_amd/libntsm_host.so: $(HOSTSRC) $(HOST)/host_capi.cpp $(HOSTHDR)
 build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp $(HOSTHDR) ntsm_amd/libntsm_hip.so
 	@mkdir -p build
 	$(CXX) $(CXXFLAGS) -o $@ $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp \
-	    -Lntsm_amd -lntsm_hip -lz -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
+	    -Lntsm_amd -lntsm_hip -lz -pthread -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
 ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_device.h include/ntsm_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ntsm_hip.hip -L/opt/rocm/lib -lrccl

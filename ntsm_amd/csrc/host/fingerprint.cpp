@@ -1,10 +1,14 @@
 #include "fingerprint.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "report.hpp"
 #include "seq_reader.hpp"
@@ -23,7 +27,7 @@ static uint64_t threshold_from(double n_distinct, double cov)
 	return (uint64_t) x;
 }
 
-void FingerPrint::die(int rc, const char *what) const
+void Feeder::die(int rc, const char *what) const
 {
 	std::cerr << "ntsmCount: " << what << ": " << ntsm_strerror(rc);
 	if (rc == NTSM_ERR_HIP) std::cerr << " (hipError " << ntsm_last_hip_error() << ")";
@@ -31,16 +35,12 @@ void FingerPrint::die(int rc, const char *what) const
 	exit(1);
 }
 
-FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
+static std::mutex g_stderr;
+
+Feeder::Feeder(const Options &opt, const SiteSet &sites, uint64_t max_hits) : m_opt(opt), m_maxCounts(max_hits)
 {
-	if (!m_sites.load(m_opt.snp, m_opt.k, m_opt.dupes, std::cerr)) {
-		std::cerr << "file " << m_opt.snp << " cannot be opened" << std::endl;   /* :493-499 */
-		exit(1);
-	}
-	if (m_opt.verbose) std::cerr << "Opening " << m_opt.snp << std::endl;
-	m_maxCounts = threshold_from((double) m_sites.n_distinct(), m_opt.covThresh);
-	if (m_sites.keys.size() > 0xFFFFFFFFull) die(NTSM_ERR_ARG, "too many site k-mers");
-	int rc = ntsm_create(&m_ctx, m_opt.device, (int) m_opt.k, m_sites.keys.data(), (uint32_t) m_sites.keys.size(),
+	if (sites.keys.size() > 0xFFFFFFFFull) die(NTSM_ERR_ARG, "too many site k-mers");
+	int rc = ntsm_create(&m_ctx, m_opt.device, (int) m_opt.k, sites.keys.data(), (uint32_t) sites.keys.size(),
 			NTSM_KEYS_CANONICAL, m_maxCounts);
 	if (rc) die(rc, "cannot create GPU context");
 	m_cfgBytes = m_opt.batch_bytes < 4096 ? 4096 : m_opt.batch_bytes;
@@ -48,9 +48,9 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 	if (rc) die(rc, "cannot size staging buffers");
 }
 
-FingerPrint::~FingerPrint() { ntsm_destroy(m_ctx); }
+Feeder::~Feeder() { ntsm_destroy(m_ctx); }
 
-void FingerPrint::flushBatch()
+void Feeder::flush()
 {
 	if (!m_bases) return;
 	int rc = ntsm_submit_staged(m_ctx, m_fill, m_nReads);
@@ -72,53 +72,102 @@ void FingerPrint::flushBatch()
 	}
 }
 
+void Feeder::feedFile(const std::string &fn)
+{
+	SeqReader rd;
+	if (!rd.open(fn)) {
+		std::lock_guard<std::mutex> lk(g_stderr);
+		std::cerr << "file " << fn << " cannot be opened" << std::endl;
+		exit(1);
+	} else if (m_opt.verbose) {
+		std::lock_guard<std::mutex> lk(g_stderr);
+		std::cerr << "Opening " << fn << std::endl;
+	}
+	int64_t l = rd.next();
+	while (l >= 0 && !m_earlyTerm) {
+		const uint64_t len = (uint64_t) l;
+		if (m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)) flush();
+		if (m_earlyTerm) break;
+		if (!m_bases) {
+			if (len + 1 > m_cfgBytes) {                              /* a read longer than a slot: grow both slots */
+				m_cfgBytes = (len + 1) + (len + 1) / 2;
+				int rc = ntsm_set_batch_capacity(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16);
+				if (rc) die(rc, "cannot grow staging buffers");
+			}
+			int rc = ntsm_staging_acquire(m_ctx, &m_bases, &m_capBytes, &m_readEnd, &m_capReads);
+			if (rc) die(rc, "cannot acquire staging");
+		}
+		memcpy(m_bases + m_fill, rd.seq_data(), len);
+		m_fill += len;
+		m_bases[m_fill] = 'N';                               /* read terminator */
+		m_readEnd[m_nReads++] = m_fill;
+		m_fill += 1;
+		l = rd.next();
+	}
+}
+
+FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
+{
+	if (!m_sites.load(m_opt.snp, m_opt.k, m_opt.dupes, std::cerr)) {
+		std::cerr << "file " << m_opt.snp << " cannot be opened" << std::endl;   /* :493-499 */
+		exit(1);
+	}
+	if (m_opt.verbose) std::cerr << "Opening " << m_opt.snp << std::endl;
+	m_maxCounts = threshold_from((double) m_sites.n_distinct(), m_opt.covThresh);
+	m_feeders.emplace_back(new Feeder(m_opt, m_sites, m_maxCounts));
+}
+
+FingerPrint::~FingerPrint() { }
+
 void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 {
-	/* The reference runs this loop under `omp parallel for` over files (:47); one file is one
-	 * thread whatever -t says, and argv order on one thread is its only deterministic schedule
-	 * (-m is order dependent), so files are consumed in order and parallelism lives on the GPU. */
-	for (const std::string &fn : filenames) {
-		SeqReader rd;
-		if (!rd.open(fn)) {
-			std::cerr << "file " << fn << " cannot be opened" << std::endl;
-			exit(1);
-		} else if (m_opt.verbose) {
-			std::cerr << "Opening " << fn << std::endl;
-		}
-		int64_t l = rd.next();
-		while (l >= 0 && !m_earlyTerm) {
-			const uint64_t len = (uint64_t) l;
-			if (m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)) flushBatch();
-			if (m_earlyTerm) break;
-			if (!m_bases) {
-				if (len + 1 > m_cfgBytes) {                              /* a read longer than a slot: grow both slots */
-					m_cfgBytes = (len + 1) + (len + 1) / 2;
-					int rc = ntsm_set_batch_capacity(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16);
-					if (rc) die(rc, "cannot grow staging buffers");
-				}
-				int rc = ntsm_staging_acquire(m_ctx, &m_bases, &m_capBytes, &m_readEnd, &m_capReads);
-				if (rc) die(rc, "cannot acquire staging");
-			}
-			memcpy(m_bases + m_fill, rd.seq_data(), len);
-			m_fill += len;
-			m_bases[m_fill] = 'N';                               /* read terminator */
-			m_readEnd[m_nReads++] = m_fill;
-			m_fill += 1;
-			l = rd.next();
-		}
+	/* The reference runs this loop under `omp parallel for` over files (:47): -t N means N files at a time.
+	 * Same here when no -m threshold is armed: N host threads, each with its own GPU context on the same
+	 * device, pull files from a shared index; per-k-mer counts are summed afterwards (order cannot matter).
+	 * With -m the reference's parallel schedule is a race; the only defined semantics is
+	 * argv order on one thread, which is what an armed run always uses. */
+	const size_t n_threads = m_maxCounts != 0 ? 1 : std::min<size_t>(std::max(1u, m_opt.threads), filenames.size());
+	if (n_threads <= 1) {
+		Feeder &f = *m_feeders[0];
+		for (const std::string &fn : filenames) f.feedFile(fn);    /* after a stop: still opened, nothing counted (:66) */
+		f.flush();
+		if (f.earlyTerm()) std::cerr << "Reached desired (-m) threshold" << std::endl;   /* :84-86 */
+		return;
 	}
-	flushBatch();
-	if (m_earlyTerm) std::cerr << "Reached desired (-m) threshold" << std::endl;   /* :84-86 */
+	m_feeders.resize(n_threads);
+	std::atomic<size_t> next(0);
+	std::vector<std::thread> pool;
+	for (size_t t = 0; t < n_threads; ++t)
+		pool.emplace_back([&, t]() {
+			if (!m_feeders[t]) m_feeders[t].reset(new Feeder(m_opt, m_sites, 0));   /* contexts are built in parallel too */
+			Feeder &f = *m_feeders[t];
+			for (size_t i = next++; i < filenames.size(); i = next++) f.feedFile(filenames[i]);
+			f.flush();
+		});
+	for (auto &th : pool) th.join();
 }
 
 void FingerPrint::fetchResults()
 {
 	if (m_fetched) return;
-	int rc = ntsm_sync(m_ctx, &m_totals);
-	if (rc) die(rc, "sync failed");
 	m_counts.assign(m_sites.keys.size(), 0);
-	rc = ntsm_counts(m_ctx, m_counts.data());
-	if (rc) die(rc, "cannot fetch counts");
+	m_totals = ntsm_totals();
+	std::vector<uint64_t> part(m_sites.keys.size());
+	for (auto &f : m_feeders) {
+		ntsm_totals t;
+		int rc = ntsm_sync(f->ctx(), &t);
+		if (rc == 0) rc = ntsm_counts(f->ctx(), part.data());
+		if (rc) {
+			std::cerr << "ntsmCount: cannot fetch counts: " << ntsm_strerror(rc) << std::endl;
+			exit(1);
+		}
+		for (size_t i = 0; i < part.size(); ++i) m_counts[i] += part[i];
+		m_totals.total_kmers += t.total_kmers;
+		m_totals.total_hits += t.total_hits;
+		m_totals.total_bases += t.total_bases;
+		m_totals.reads_consumed += t.reads_consumed;
+		m_totals.early_stop |= t.early_stop;
+	}
 	m_fetched = true;
 }
 

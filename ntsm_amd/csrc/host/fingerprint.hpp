@@ -8,6 +8,7 @@
 #define NTSM_FINGERPRINT_HPP
 #include <cstdint>
 #include <iosfwd>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,31 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	uint64_t batch_bytes = 64ull << 20;    /* staging capacity per slot */
 };
 
+/* One GPU context plus the staging batch being filled for it.  A Feeder is driven by one thread. */
+class Feeder {
+public:
+	Feeder(const Options &opt, const SiteSet &sites, uint64_t max_hits);
+	~Feeder();
+	Feeder(const Feeder &) = delete;
+	Feeder &operator=(const Feeder &) = delete;
+	/* Count every record of one file (src/FingerPrint.hpp:49-81); stops early once the -m threshold tripped. */
+	void feedFile(const std::string &path);
+	void flush();
+	bool earlyTerm() const { return m_earlyTerm; }
+	ntsm_ctx *ctx() const { return m_ctx; }
+
+private:
+	[[noreturn]] void die(int rc, const char *what) const;
+	const Options &m_opt;
+	ntsm_ctx *m_ctx = nullptr;
+	uint64_t m_maxCounts = 0;
+	uint8_t *m_bases = nullptr;
+	uint64_t *m_readEnd = nullptr;
+	uint64_t m_capBytes = 0, m_capReads = 0, m_fill = 0, m_cfgBytes = 0;
+	uint32_t m_nReads = 0;
+	bool m_earlyTerm = false;
+};
+
 class FingerPrint {
 public:
 	explicit FingerPrint(const Options &opt);            /* FingerPrint(), :35-44 */
@@ -39,20 +65,12 @@ public:
 	uint64_t maxCounts() const { return m_maxCounts; }
 
 private:
-	void flushBatch();
 	void fetchResults();
-	[[noreturn]] void die(int rc, const char *what) const;
 
 	Options m_opt;
 	SiteSet m_sites;
-	ntsm_ctx *m_ctx = nullptr;
 	uint64_t m_maxCounts = 0;
-	/* current staging batch */
-	uint8_t *m_bases = nullptr;
-	uint64_t *m_readEnd = nullptr;
-	uint64_t m_capBytes = 0, m_capReads = 0, m_fill = 0, m_cfgBytes = 0;
-	uint32_t m_nReads = 0;
-	bool m_earlyTerm = false;
+	std::vector<std::unique_ptr<Feeder>> m_feeders;      /* [0] always exists; more with -t N and several files */
 	/* results */
 	bool m_fetched = false;
 	ntsm_totals m_totals {};

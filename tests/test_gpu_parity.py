@@ -407,3 +407,21 @@ def test_early_stop_across_chunks(nt, n10):
     assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases)
     assert np.array_equal(ctx.counts(), fp.kmers()[2])
     ctx.close()
+
+
+def test_cli_threads_over_files(nt, tmp_path):
+    """-t N counts N files at a time (the reference's omp-over-files, src/FingerPrint.hpp:47), each host thread with
+    its own GPU context; the summed result is the single-thread bytes.  With -m the run stays on one thread."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    inp = os.path.join(G, "inputs")
+    files = ["reads2k.fq", "reads600.fq.gz", "reads3.fq", "edge.fa", "long.fa", "odd.fq", "multiline.fa"]
+    base = subprocess.run([exe, "-s", "sites200.fa"] + files, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert base.returncode == 0
+    for t in ("2", "5", "16"):
+        p = subprocess.run([exe, "-s", "sites200.fa", "-t", t] + files, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr[-400:]
+        assert p.stdout == base.stdout
+        assert _summary(p.stderr) == _summary(base.stderr)
+    c = next(x for x in CASES if x["name"] == "m_file_boundary_continue")
+    p = subprocess.run([exe] + c["args"] + ["-t", "8"] + c["files"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == open(os.path.join(G, "expected", c["stdout"]), "rb").read()

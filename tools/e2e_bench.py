@@ -39,3 +39,16 @@ p = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", sp, fq], std
 dt = time.perf_counter() - t0
 print("CLI end to end: %.2f s for %d reads -> %.3f Gbases/s (includes site-table build)" % (dt, n_cli, n_cli * 150 / dt / 1e9))
 print(p.stderr.decode()[-400:])
+
+# -t N over N files (reference semantics: parallel over files)
+nf = 8
+parts = []
+t0 = time.perf_counter()
+for i in range(nf):
+    fp_ = os.path.join(tmp, "part%d.fq" % i); s.write_fastq(fp_, i * (n_cli // nf), n_cli // nf); parts.append(fp_)
+print("wrote %d files in %.1f s" % (nf, time.perf_counter() - t0))
+for t in (1, 8):
+    t0 = time.perf_counter()
+    p = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", sp, "-t", str(t)] + parts, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t0
+    print("CLI %d files -t %d: %.2f s -> %.3f Gbases/s" % (nf, t, dt, (n_cli // nf) * nf * 150 / dt / 1e9))
