@@ -37,10 +37,10 @@ void Feeder::die(int rc, const char *what) const
 
 static std::mutex g_stderr;
 
-Feeder::Feeder(const Options &opt, const SiteSet &sites, uint64_t max_hits) : m_opt(opt), m_maxCounts(max_hits)
+Feeder::Feeder(const Options &opt, const SiteSet &sites, uint64_t max_hits, int device) : m_opt(opt), m_maxCounts(max_hits)
 {
 	if (sites.keys.size() > 0xFFFFFFFFull) die(NTSM_ERR_ARG, "too many site k-mers");
-	int rc = ntsm_create(&m_ctx, m_opt.device, (int) m_opt.k, sites.keys.data(), (uint32_t) sites.keys.size(),
+	int rc = ntsm_create(&m_ctx, device, (int) m_opt.k, sites.keys.data(), (uint32_t) sites.keys.size(),
 			NTSM_KEYS_CANONICAL, m_maxCounts);
 	if (rc) die(rc, "cannot create GPU context");
 	m_cfgBytes = m_opt.batch_bytes < 4096 ? 4096 : m_opt.batch_bytes;
@@ -114,7 +114,8 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 	}
 	if (m_opt.verbose) std::cerr << "Opening " << m_opt.snp << std::endl;
 	m_maxCounts = threshold_from((double) m_sites.n_distinct(), m_opt.covThresh);
-	m_feeders.emplace_back(new Feeder(m_opt, m_sites, m_maxCounts));
+	if (m_opt.devices.empty()) m_opt.devices.push_back(m_opt.device);
+	m_feeders.emplace_back(new Feeder(m_opt, m_sites, m_maxCounts, m_opt.devices[0]));
 }
 
 FingerPrint::~FingerPrint() { }
@@ -139,7 +140,8 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 	std::vector<std::thread> pool;
 	for (size_t t = 0; t < n_threads; ++t)
 		pool.emplace_back([&, t]() {
-			if (!m_feeders[t]) m_feeders[t].reset(new Feeder(m_opt, m_sites, 0));   /* contexts are built in parallel too */
+			if (!m_feeders[t])                                  /* contexts are built in parallel too, spread over the -g devices */
+				m_feeders[t].reset(new Feeder(m_opt, m_sites, 0, m_opt.devices[t % m_opt.devices.size()]));
 			Feeder &f = *m_feeders[t];
 			for (size_t i = next++; i < filenames.size(); i = next++) f.feedFile(filenames[i]);
 			f.flush();

@@ -26,13 +26,14 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	double covThresh = 1.7976931348623157e308;   /* DBL_MAX: never stop */
 	bool dupes = false;
 	int device = 0;                        /* HIP device (new; the reference has no device concept) */
+	std::vector<int> devices;              /* -g 0,1,...: host threads (-t) are spread round-robin over these devices */
 	uint64_t batch_bytes = 64ull << 20;    /* staging capacity per slot */
 };
 
 /* One GPU context plus the staging batch being filled for it.  A Feeder is driven by one thread. */
 class Feeder {
 public:
-	Feeder(const Options &opt, const SiteSet &sites, uint64_t max_hits);
+	Feeder(const Options &opt, const SiteSet &sites, uint64_t max_hits, int device);
 	~Feeder();
 	Feeder(const Feeder &) = delete;
 	Feeder &operator=(const Feeder &) = delete;

@@ -3,7 +3,8 @@
  *   ntsmCount -s sites.fa [-t N] [-m COV] [-o summary] [-d] [-k K] [-v] reads.fq[.gz] ... > counts.txt
  * stdout: "#@TK", "#@KS" headers + one row per site (countAT/countCG = max per-k-mer count of the
  * allele).  stderr: collision warnings, the six summary lines, "Time: .. s Memory: .. kbytes".
- * New, optional: -g/--gpu INT selects the HIP device (default 0).
+ * New, optional: -g/--gpu INT[,INT...] selects the HIP device(s) (default 0); with -t N and several files the host
+ * threads are spread round-robin over the listed devices and the per-k-mer counts are summed on the host.
  */
 #include <getopt.h>
 
@@ -51,7 +52,8 @@ static void printHelpDialog()
 		"  -s, --snp = STR        Interleaved fasta of SNP sites to\n"
 		"                         k-merize. [required]\n"
 		"  -k, --kmer = INT       k-mer size used. [19]\n"
-		"  -g, --gpu = INT        HIP device to run on. [0]\n"
+		"  -g, --gpu = INT[,INT]  HIP device(s) to run on; with -t N the host\n"
+		"                         threads are spread over them. [0]\n"
 		"  -h, --help             Display this dialog.\n"
 		"  -v, --verbose          Display verbose output.\n"
 		"      --version          Print version information.\n";
@@ -89,7 +91,19 @@ int main(int argc, char *argv[])
 		case 'm': if (!parse(optarg, opt.covThresh)) { std::cerr << "Error - Invalid parameter m: " << optarg << std::endl; return 0; } break;
 		case 'k': if (!parse(optarg, opt.k)) { std::cerr << "Error - Invalid parameter k: " << optarg << std::endl; return 0; } break;
 		case 't': if (!parse(optarg, opt.threads)) { std::cerr << "Error - Invalid parameter t: " << optarg << std::endl; return 0; } break;
-		case 'g': if (!parse(optarg, opt.device)) { std::cerr << "Error - Invalid parameter g: " << optarg << std::endl; return 0; } break;
+		case 'g': {                                    /* one device or a comma-separated list */
+			std::stringstream list(optarg);
+			std::string item;
+			opt.devices.clear();
+			while (std::getline(list, item, ',')) {
+				int d;
+				if (!parse(item.c_str(), d) || d < 0) { std::cerr << "Error - Invalid parameter g: " << optarg << std::endl; return 0; }
+				opt.devices.push_back(d);
+			}
+			if (opt.devices.empty()) { std::cerr << "Error - Invalid parameter g: " << optarg << std::endl; return 0; }
+			opt.device = opt.devices[0];
+			break;
+		}
 		case 'v': opt.verbose++; break;
 		case '?': die = true; break;
 		}

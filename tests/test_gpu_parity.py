@@ -371,6 +371,9 @@ def test_merge_counts_single_rank_roundtrip(nt, n10):
     t1 = ctx.sync()
     assert np.array_equal(ctx.counts(), 2 * c0)
     assert (t1.total_kmers, t1.total_hits, t1.total_bases, t1.reads_consumed) == (2 * t0.total_kmers, 2 * t0.total_hits, 2 * t0.total_bases, 2 * t0.reads_consumed)
+    import ctypes
+    arr = (ctypes.c_void_p * 1)(ctx._h)
+    assert nt.capi.H.ntsm_allreduce(arr, 1) == 0         # single-process entry point, one context: a no-op merge
     merge_counts(ctx)                                    # no process group: idempotent on an already merged context
     assert np.array_equal(ctx.counts(), 2 * c0)
     ctx.submit(s.host_bytes(0, 10), s.read_end(10))      # new local work invalidates the merged view
@@ -417,8 +420,8 @@ def test_cli_threads_over_files(nt, tmp_path):
     files = ["reads2k.fq", "reads600.fq.gz", "reads3.fq", "edge.fa", "long.fa", "odd.fq", "multiline.fa"]
     base = subprocess.run([exe, "-s", "sites200.fa"] + files, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert base.returncode == 0
-    for t in ("2", "5", "16"):
-        p = subprocess.run([exe, "-s", "sites200.fa", "-t", t] + files, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    for t in ("2", "5", "16", "4 -g 0,0"):
+        p = subprocess.run([exe, "-s", "sites200.fa", "-t"] + t.split() + files, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 0, p.stderr[-400:]
         assert p.stdout == base.stdout
         assert _summary(p.stderr) == _summary(base.stderr)
