@@ -216,8 +216,11 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 #ifndef NTSM_FAST_BRANCHLESS_PUSH
 #define NTSM_FAST_BRANCHLESS_PUSH 0
 #endif
-#ifndef NTSM_FAST_PIPELINE
-#define NTSM_FAST_PIPELINE 0
+#ifndef NTSM_FAST_EARLY_LOADS
+#define NTSM_FAST_EARLY_LOADS 1                        /* issue each filter load right after its offset is known (+2 %) */
+#endif
+#ifndef NTSM_FAST_LDS_PREFETCH
+#define NTSM_FAST_LDS_PREFETCH 1                       /* base-table reads of block b+1 issued before phase C of block b */
 #endif
 constexpr int kFastC = 128;
 constexpr int kQueueCap = 128;                         /* < 64 left over + one position's burst of <= 64 */
@@ -381,11 +384,12 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 		 * decides per position whether the minimizer changed (nd) and issues the 8 filter-block loads
 		 * (lanes that keep their block all read block 0: one request per wave instruction). */
 		struct BlockState { uint32_t f3[8], r[8]; bool ok[8], nd[8]; uint2 bl[8]; };
-		auto phase_a = [&](const uint2 v, BlockState &B) {
+		auto lut_reads = [&](const uint2 v, uint2 (&e8)[8]) {   /* the 8 table reads of one block issue together */
 			const uint32_t w[2] = { v.x, v.y };
-			uint2 e8[8];
 #pragma unroll
 			for (int j = 0; j < 8; ++j) e8[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
+		};
+		auto phase_a = [&](const uint2 (&e8)[8], BlockState &B) {
 			uint32_t gg[8], fh[8], idx[8], pm = 0xFFFFFFFFu;
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
@@ -405,16 +409,24 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				mz_prev = mz;
 				ok_prev = B.ok[j];
 				nk += B.ok[j] ? 1u : 0u;
+#if NTSM_FAST_EARLY_LOADS
+				{   /* issue each block load as soon as its offset is known: earlier positions get the rest of the block as cover */
+					const u32x2 bv = __builtin_amdgcn_raw_buffer_load_b64(blk_rsrc, (int) idx[j], 0, 0);
+					B.bl[j] = make_uint2(bv.x, bv.y);
+				}
+#endif
 			}
 			fc0 = fh[5]; fc1 = fh[6]; fc2 = fh[7];
 			sprev[7] = gg[7];
 #pragma unroll
 			for (int j = 6; j >= 9 - NTSM_FAST_W; --j) sprev[j] = min(gg[j], sprev[j + 1]);
+#if !NTSM_FAST_EARLY_LOADS
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {                      /* buffer loads: 32-bit byte offset, range-checked by the descriptor */
 				const u32x2 bv = __builtin_amdgcn_raw_buffer_load_b64(blk_rsrc, (int) idx[j], 0, 0);
 				B.bl[j] = make_uint2(bv.x, bv.y);
 			}
+#endif
 		};
 		/* Phase C: two-bit test against the (possibly just fetched) block; positives go to the queue */
 		auto phase_c = [&](const BlockState &B, const int pos0) {
@@ -437,26 +449,27 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			}
 		};
 
-#if NTSM_FAST_PIPELINE
-		/* software pipeline: block b+1's phase A (and its loads) run before block b's phase C, so every
-		 * filter load has a full block of independent work to hide behind */
-		BlockState S0, S1;
-		phase_a(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, 0)), S0);
-#pragma unroll 1
-		for (int b = 0; b < NB; b += 2) {
-			phase_a(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, (b + 1) * 8)), S1);
-			phase_c(S0, t * C + b * 8);
-			if (b + 2 < NB) phase_a(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, (b + 2) * 8)), S0);
-			phase_c(S1, t * C + b * 8 + 8);
-		}
-#else
 		BlockState S;
+		uint2 e8[8];
+		/* LDS prefetch (not in the -m variant, which has no registers to spare): the tile word of block b+2 and
+		 * the base-table entries of block b+1 are requested while block b is still being tested, so a block never
+		 * starts by waiting for two LDS round trips */
+		constexpr bool kPrefetch = NTSM_FAST_LDS_PREFETCH && !PER_READ;
+		uint2 wn = make_uint2(0, 0);
+		if (kPrefetch) {
+			lut_reads(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, 0)), e8);
+			wn = *reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, 8));
+		}
 #pragma unroll 1
 		for (int b = 0; b < NB; ++b) {
-			phase_a(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, b * 8)), S);
+			if (!kPrefetch) lut_reads(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, b * 8)), e8);
+			phase_a(e8, S);
+			if (kPrefetch) {
+				if (b + 1 < NB) lut_reads(wn, e8);
+				if (b + 2 < NB) wn = *reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, (b + 2) * 8));
+			}
 			phase_c(S, t * C + b * 8);
 		}
-#endif
 		drain(true);
 #undef NTSM_STEP
 #undef NTSM_MMER_G
