@@ -216,6 +216,14 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 #ifndef NTSM_FAST_BRANCHLESS_PUSH
 #define NTSM_FAST_BRANCHLESS_PUSH 0
 #endif
+#ifndef NTSM_FAST_ASM_LSHLOR
+#define NTSM_FAST_ASM_LSHLOR 0
+#endif
+#if NTSM_FAST_ASM_LSHLOR
+#define NTSM_F_UPDATE(c_) asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(F) : "v"(F), "v"(c_));
+#else
+#define NTSM_F_UPDATE(c_) F = (F << 2) | (c_);
+#endif
 #ifndef NTSM_FAST_EARLY_LOADS
 #define NTSM_FAST_EARLY_LOADS 1                        /* issue each filter load right after its offset is known (+2 %) */
 #endif
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 		uint32_t qn = 0;                                    /* wave-uniform queue fill */
 #define NTSM_STEP(e_)                                                                     \
 		{                                                                                 \
-			F = (F << 2) | (e_).x;                                                        \
+			NTSM_F_UPDATE((e_).x)                                                         \
 			R = __builtin_amdgcn_alignbit((e_).y, R, 2);                                  \
 			inv = __builtin_amdgcn_alignbit(inv, (e_).y, 31);                             \
 		}
