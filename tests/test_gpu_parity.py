@@ -428,3 +428,36 @@ def test_cli_threads_over_files(nt, tmp_path):
     c = next(x for x in CASES if x["name"] == "m_file_boundary_continue")
     p = subprocess.run([exe] + c["args"] + ["-t", "8"] + c["files"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0 and p.stdout == open(os.path.join(G, "expected", c["stdout"]), "rb").read()
+
+
+def test_fuzz_arbitrary_bytes(nt, tmp_path):
+    """Arbitrary byte soup (all 256 values, long valid runs, runs of raw 0..3 codes, lowercase, U): both kernels
+    against the oracle, with site k-mers cut out of the stream itself so that hits are frequent."""
+    rng = np.random.default_rng(2024)
+    for k in (19, 7, 32):
+        n = 400_000
+        letters = np.frombuffer(b"ACGTacgtUu\x00\x01\x02\x03", dtype=np.uint8)
+        buf = letters[rng.integers(0, len(letters), n)].copy()
+        junk = rng.random(n) < 0.01
+        buf[junk] = rng.integers(0, 256, int(junk.sum()), dtype=np.uint8)
+        buf[rng.integers(0, n, 300)] = ord("N")
+        path = str(tmp_path / ("fz%d.fa" % k))
+        with open(path, "wb") as f:                         # sites: windows of the stream (any bytes but > and newline)
+            for i in range(400):
+                a = int(rng.integers(0, n - 64))
+                seg = bytes(buf[a:a + int(rng.integers(k, 60))]).replace(b">", b"A").replace(b"\n", b"C").replace(b"\r", b"G").replace(b"@", b"T").replace(b"+", b"A")
+                f.write(b">s%d\n" % (i // 2) + seg + b"\n")
+        sites = nt.Sites(path, k=k, allow_dupes=True)
+        fp = OracleFP(path, k=k, dupes=True)
+        fp.L.ntsm_oracle_fp_insert_count(fp.h, buf.tobytes(), n)
+        ends = np.array([n], dtype=np.uint64)
+        flat = np.concatenate([buf, np.frombuffer(b"N", dtype=np.uint8)])
+        for variant in (0, 1):
+            ctx = nt.Context(sites.keys, k=k)
+            ctx.set_kernel(variant)
+            ctx.submit(flat, ends)
+            t = ctx.sync()
+            assert np.array_equal(ctx.counts(), fp.kmers()[2]), (k, variant)
+            assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, n), (k, variant)
+            ctx.close()
+        assert fp.total_hits > 100
