@@ -62,26 +62,30 @@ NTSM_DHD uint32_t ntsm_mmer_hash(uint32_t cm)
  * index is a multiply-shift range reduction: h = 24x24-bit multiply (full rate on CDNA) of the low 24 bits of
  * the order hash -- a bijective image of the 12-mer that the min-selection leaves unbiased --, q = its top
  * (e + slack) bits, index = (q * mult) >> slack. */
-struct NtsmBlockMap { uint32_t qshift, mult, sshift; };      /* q = h >> qshift; off = ((q * mult) >> sshift) & ~7 */
+struct NtsmBlockMap { uint32_t qshift, mult, sshift; };      /* q = h >> qshift; off = ((q * mult) >> sshift) & ~15 */
 NTSM_DHD uint32_t ntsm_block_off(uint32_t mz, NtsmBlockMap m)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	const uint32_t h = (uint32_t) __umul24(mz, 0xC2B2AFu);      /* __umul24 is declared int in HIP */
-	return ((uint32_t) __umul24(h >> m.qshift, m.mult) >> m.sshift) & ~7u;
+	return ((uint32_t) __umul24(h >> m.qshift, m.mult) >> m.sshift) & ~15u;
 #else
 	const uint32_t h = (uint32_t) ((uint64_t) (mz & 0xFFFFFFu) * 0xC2B2AFu);
-	return ((uint32_t) ((uint64_t) (h >> m.qshift) * m.mult) >> m.sshift) & ~7u;
+	return ((uint32_t) ((uint64_t) (h >> m.qshift) * m.mult) >> m.sshift) & ~15u;
 #endif
 }
-/* Two filter bits per site k-mer, one in each 32-bit half of the block: bit (u >> 27) of the low word
- * and bit ((u >> 22) & 31) of the high word, u = fh + rh.  fh / rh are the top 32 bits of the 38-bit
- * forward and reverse-complement codes (code >> 6): together they cover all 19 bases, the sum is
- * symmetric in the two strands (no canonical min in the hot loop), and its carry chain already mixes
- * well enough that the top bits need no further hashing (measured false-positive rate 1.9 % with a
- * 4 MiB filter on the hs_n10_like set, better than a multiplicative hash of the same sum). */
-NTSM_DHD uint32_t ntsm_kmer_bits(uint32_t fh, uint32_t rh) { return fh + rh; }
-#define NTSM_KBIT_LO(u) ((u) >> 27)
-#define NTSM_KBIT_HI(u) (((u) >> 22) & 31u)
+/* Four filter bits per site k-mer, one in each 32-bit word of its 128-bit block.  u = fh + rh where fh / rh are the
+ * top 32 bits of the 38-bit forward and reverse-complement codes (code >> 6): together they cover all 19 bases
+ * and the sum is symmetric in the two strands (no canonical min in the hot loop); um = u * odd constant spreads
+ * single-base differences over all bits.  The four 5-bit positions are byte-aligned fields (u byte 3, um bytes 3,
+ * 2, 1) so that the shifts can take them with a byte select.  Measured false-positive rate on the hs_n10_like
+ * set with a 3 MiB filter: 1.1 % (two bits in a 64-bit block: 2.6 %) -- read minimizers and site minimizers
+ * favour the same m-mers, so the blocks that queries hit are the loaded ones and wide blocks pay off. */
+NTSM_DHD uint32_t ntsm_kmer_sum(uint32_t fh, uint32_t rh) { return fh + rh; }
+NTSM_DHD uint32_t ntsm_kmer_mix(uint32_t u) { return u * 0x9E3779B1u; }
+#define NTSM_KBIT0(u) (((u) >> 24) & 31u)
+#define NTSM_KBIT1(um) (((um) >> 24) & 31u)
+#define NTSM_KBIT2(um) (((um) >> 16) & 31u)
+#define NTSM_KBIT3(um) (((um) >> 8) & 31u)
 /* a minimizer value that no 12-mer produces (0x9E3779 * 2^24 mod 2^32): "no block cached yet" */
 #define NTSM_NO_MINIMIZER 0x79000000u
 
@@ -104,7 +108,7 @@ struct NtsmCountParams {
 	uint32_t fshift, bshift;           /* bit index = h1 >> fshift ; bucket = h >> bshift */
 	const uint8_t *lut;                /* 256-byte base table, vendor/KseqHashIterator.hpp:114-127 */
 	const uint2 *lut64;                /* fast path: per byte { code, (3 - code) | invalid << 31 } */
-	const unsigned long long *blocks;  /* k = 19 fast path: minimizer-addressed 64-bit filter blocks */
+	const uint4 *blocks;               /* k = 19 fast path: minimizer-addressed 128-bit filter blocks */
 	NtsmBlockMap blk_map;              /* minimizer -> filter block offset */
 	const uint32_t *prefilter;         /* fast path, drain only: plain 2-bit Bloom over canonical codes (L2 resident) */
 	uint32_t pf_shift;                 /* word index = h1(fold) >> pf_shift; bits = h2(fold) & 31, (h2 >> 5) & 31 */

@@ -44,6 +44,7 @@ constexpr int kThreads = 256;
 constexpr uint32_t kN4 = 0x4E4E4E4Eu;      /* "NNNN" */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint4 ntsm_load_vec(const NtsmCountParams &p, long long o)
 {
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 #define NTSM_FAST_EARLY_LOADS 1                        /* issue each filter load right after its offset is known (+2 %) */
 #endif
 #ifndef NTSM_FAST_LDS_PREFETCH
-#define NTSM_FAST_LDS_PREFETCH 1                       /* base-table reads of block b+1 issued before phase C of block b */
+#define NTSM_FAST_LDS_PREFETCH 0                       /* base-table reads of block b+1 issued before phase C of block b (+1 %, 16 VGPRs: spent on the 128-bit filter blocks instead) */
 #endif
 constexpr int kFastC = 128;
 constexpr int kQueueCap = 128;                         /* < 64 left over + one position's burst of <= 64 */
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 	const NtsmBlockMap blk_map = p.blk_map;
 	/* buffer resource over the filter blocks: one instruction per load, 32-bit byte offset */
 	const __amdgpu_buffer_rsrc_t blk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-			const_cast<unsigned long long *>(p.blocks), 0, (int) p.blk_bytes, 0x00020000);
+			const_cast<uint4 *>(p.blocks), 0, (int) p.blk_bytes, 0x00020000);
 	uint32_t nk = 0, nh = 0;
 
 	for (unsigned long long ti = blockIdx.x; ti < p.n_tiles; ti += gridDim.x) {
@@ -308,7 +309,8 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 #pragma unroll
 			for (int i = 6; i >= 9 - NTSM_FAST_W; --i) sprev[i] = min(gw[i], sprev[i + 1]);
 		}
-		uint32_t mz_prev = 0, cur_lo = 0, cur_hi = 0;
+		uint32_t mz_prev = 0;
+		uint4 cur = make_uint4(0, 0, 0, 0);                  /* the lane's cached 128-bit filter block */
 		bool ok_prev = false;                               /* nothing cached at the start of a chunk */
 
 		/* Drain: look up queued positives 64 at a time, as a three-stage pipeline spread over consecutive
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 		/* Phase A of one 8-position block: roll, 12-mer order hashes, sliding minimum, k-mer bit hash;
 		 * decides per position whether the minimizer changed (nd) and issues the 8 filter-block loads
 		 * (lanes that keep their block all read block 0: one request per wave instruction). */
-		struct BlockState { uint32_t f3[8], r[8]; bool ok[8], nd[8]; uint2 bl[8]; };
+		struct BlockState { uint32_t f3[8], r[8]; bool ok[8], nd[8]; uint4 bl[8]; };
 		auto lut_reads = [&](const uint2 v, uint2 (&e8)[8]) {   /* the 8 table reads of one block issue together */
 			const uint32_t w[2] = { v.x, v.y };
 #pragma unroll
@@ -419,8 +421,8 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				nk += B.ok[j] ? 1u : 0u;
 #if NTSM_FAST_EARLY_LOADS
 				{   /* issue each block load as soon as its offset is known: earlier positions get the rest of the block as cover */
-					const u32x2 bv = __builtin_amdgcn_raw_buffer_load_b64(blk_rsrc, (int) idx[j], 0, 0);
-					B.bl[j] = make_uint2(bv.x, bv.y);
+					const u32x4v bv = __builtin_amdgcn_raw_buffer_load_b128(blk_rsrc, (int) idx[j], 0, 0);
+					B.bl[j] = make_uint4(bv.x, bv.y, bv.z, bv.w);
 				}
 #endif
 			}
@@ -431,8 +433,8 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 #if !NTSM_FAST_EARLY_LOADS
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {                      /* buffer loads: 32-bit byte offset, range-checked by the descriptor */
-				const u32x2 bv = __builtin_amdgcn_raw_buffer_load_b64(blk_rsrc, (int) idx[j], 0, 0);
-				B.bl[j] = make_uint2(bv.x, bv.y);
+				const u32x4v bv = __builtin_amdgcn_raw_buffer_load_b128(blk_rsrc, (int) idx[j], 0, 0);
+				B.bl[j] = make_uint4(bv.x, bv.y, bv.z, bv.w);
 			}
 #endif
 		};
@@ -440,10 +442,13 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 		auto phase_c = [&](const BlockState &B, const int pos0) {
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
-				cur_lo = B.nd[j] ? B.bl[j].x : cur_lo;
-				cur_hi = B.nd[j] ? B.bl[j].y : cur_hi;
-				const uint32_t kb = ntsm_kmer_bits(B.f3[j], B.r[j]);
-				const bool pass = B.ok[j] & (((cur_lo >> NTSM_KBIT_LO(kb)) & (cur_hi >> NTSM_KBIT_HI(kb)) & 1u) != 0);
+				cur.x = B.nd[j] ? B.bl[j].x : cur.x;
+				cur.y = B.nd[j] ? B.bl[j].y : cur.y;
+				cur.z = B.nd[j] ? B.bl[j].z : cur.z;
+				cur.w = B.nd[j] ? B.bl[j].w : cur.w;
+				const uint32_t u = ntsm_kmer_sum(B.f3[j], B.r[j]), um = ntsm_kmer_mix(u);
+				const bool pass = B.ok[j] & (((cur.x >> NTSM_KBIT0(u)) & (cur.y >> NTSM_KBIT1(um)) & (cur.z >> NTSM_KBIT2(um)) &
+						(cur.w >> NTSM_KBIT3(um)) & 1u) != 0);
 				const unsigned long long m = __ballot(pass);
 				if (m) {
 					if (pass) {
@@ -574,8 +579,8 @@ struct ntsm_ctx {
 	uint2 *d_lut64 = nullptr;
 	uint32_t filter_log2 = 0, bucket_log2 = 0;
 	uint64_t n_slots = 0;
-	unsigned long long *d_blocks = nullptr;    /* k = 19 fast path: minimizer-addressed filter blocks */
-	uint64_t n_blocks = 0;                     /* number of 64-bit filter blocks: mult * 2^e, mult in {1, 3} */
+	uint4 *d_blocks = nullptr;                 /* k = 19 fast path: minimizer-addressed 128-bit filter blocks */
+	uint64_t n_blocks = 0;                     /* number of 128-bit filter blocks: mult * 2^e, mult in {1, 3} */
 	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
 	uint32_t prefilter_log2 = 0;               /* log2(bits) */
 	NtsmBlockMap blk_map = { 0, 1, 0 };
@@ -669,26 +674,26 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	/* k = 19: minimizer-addressed blocked filter.  Size = smallest of {2^e, 3 * 2^(e-2)} blocks with at least
 	 * 12 bits per key: 3 MiB for the 1.54 M-key human set -- it must leave room in the 4 MiB per-XCD L2 for the
 	 * read stream and the bucket lines, a full 4 MiB filter misses L2 on 18 % of its reads. */
-	std::vector<unsigned long long> blocks;
+	std::vector<uint32_t> blocks;                          /* 4 words per block */
 	if (c->k == NTSM_FAST_K) {
 		uint32_t e = 6, mult = 1;
 		if (filter_log2_req >= 100 && filter_log2_req <= 130) {          /* 100 + v: 3 * 2^v bits */
-			mult = 3; e = (uint32_t) (filter_log2_req - 100) - 6;
+			mult = 3; e = (uint32_t) (filter_log2_req - 100) - 7;
 		} else if (filter_log2_req >= 10 && filter_log2_req <= 30) {
-			e = (uint32_t) filter_log2_req - 6;
+			e = (uint32_t) filter_log2_req - 7;
 		} else {
-			const uint64_t want = (12ull * n + 63) / 64;                  /* blocks */
+			const uint64_t want = (12ull * n + 127) / 128;                /* blocks */
 			while ((1ull << e) < want && e < 21) ++e;
 			if (e > 8 && (3ull << (e - 2)) >= want) { mult = 3; e -= 2; }   /* 0.75 * 2^e is enough */
 		}
-		if (e > 21) e = 21;
+		if (e > 20) e = 20;
 		if (e < 4) e = 4;
-		const uint32_t slack = 24 - e < 6 ? 24 - e : 6;                   /* e + slack <= 24 (mul24 operand), slack >= 3 */
+		const uint32_t slack = 24 - e < 6 ? 24 - e : 6;                   /* e + slack <= 24 (mul24 operand), slack >= 4 */
 		c->n_blocks = (uint64_t) mult << e;
 		c->blk_map.qshift = 32 - (e + slack);
 		c->blk_map.mult = mult;
-		c->blk_map.sshift = slack - 3;
-		blocks.assign(c->n_blocks, 0ull);
+		c->blk_map.sshift = slack - 4;
+		blocks.assign(c->n_blocks * 4, 0u);
 		for (uint32_t i = 0; i < n; ++i) {
 			const uint64_t x = c->canon[i];
 			uint64_t rc = 0;
@@ -700,10 +705,14 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 				for (int b = 0; b < NTSM_FAST_M; ++b) rsub |= (3u - ((sub >> (2 * b)) & 3u)) << (2 * (NTSM_FAST_M - 1 - b));
 				mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
 			}
-			const uint32_t kb = ntsm_kmer_bits((uint32_t) (x >> 6), (uint32_t) (rc >> 6));
-			blocks[ntsm_block_off(mz, c->blk_map) >> 3] |= (1ull << NTSM_KBIT_LO(kb)) | (1ull << (32u + NTSM_KBIT_HI(kb)));
+			const uint32_t u = ntsm_kmer_sum((uint32_t) (x >> 6), (uint32_t) (rc >> 6)), um = ntsm_kmer_mix(u);
+			uint32_t *blk = &blocks[(ntsm_block_off(mz, c->blk_map) >> 4) * 4];
+			blk[0] |= 1u << NTSM_KBIT0(u);
+			blk[1] |= 1u << NTSM_KBIT1(um);
+			blk[2] |= 1u << NTSM_KBIT2(um);
+			blk[3] |= 1u << NTSM_KBIT3(um);
 		}
-		if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0ull);   /* ablation only: wrong counts */
+		if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0u);   /* ablation only: wrong counts */
 	}
 	/* second-level filter of the fast path: plain Bloom, 2 bits per key in one 32-bit word, >= 5 bits per key
 	 * (1 MiB for the human set: with the 3 MiB first level it still fits the 4 MiB per-XCD L2) */
@@ -733,8 +742,8 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		HIPCHK(hipMemcpy(c->d_prefilter, prefilter.data(), prefilter.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
 	if (!blocks.empty()) {
-		HIPCHK(hipMalloc(&c->d_blocks, blocks.size() * sizeof(unsigned long long)));
-		HIPCHK(hipMemcpy(c->d_blocks, blocks.data(), blocks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+		HIPCHK(hipMalloc(&c->d_blocks, blocks.size() * sizeof(uint32_t)));
+		HIPCHK(hipMemcpy(c->d_blocks, blocks.data(), blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
 	if (c->d_filter) (void) hipFree(c->d_filter);
 	if (c->d_keys) (void) hipFree(c->d_keys);
@@ -810,7 +819,7 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.prefilter = c->d_prefilter;
 	if (const char *dv = getenv("NTSM_DEBUG_KERNEL")) p.debug = (uint32_t) atoi(dv);
 	p.pf_shift = 32 - (c->prefilter_log2 - 5);
-	p.blk_bytes = (uint32_t) (c->n_blocks * 8);
+	p.blk_bytes = (uint32_t) (c->n_blocks * 16);
 	const bool fast = c->k == NTSM_FAST_K && c->d_blocks && c->kernel_variant != 1;
 	uint64_t grid = c->grid_blocks > 0 ? (uint64_t) c->grid_blocks : (uint64_t) c->n_cu * 4;
 	if (grid > p.n_tiles) grid = p.n_tiles;
