@@ -131,23 +131,24 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 			}
 		}
 		const uint8_t *own = tile + (t + 1) * ROW;
-		for (int g = 0; g < VPT; ++g) {
-			const uint4 v = *reinterpret_cast<const uint4 *>(own + 16 * g);
-			const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-			unsigned long long cn[16];
-			uint32_t hh[16], fwd[16];
-			bool ok[16];
+#pragma unroll 1
+		for (int g = 0; g < 2 * VPT; ++g) {                  /* 8 positions per step: half the live registers of a 16-wide step */
+			const uint2 v = *reinterpret_cast<const uint2 *>(own + 8 * g);
+			const uint32_t w[2] = { v.x, v.y };
+			unsigned long long cn[8];
+			uint32_t hh[8], fwd[8];
+			bool ok[8];
 #pragma unroll
-			for (int i = 0; i < 16; ++i) {
+			for (int i = 0; i < 8; ++i) {
 				NTSM_ROLL((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu)
 				ok[i] = (inv & kmask) == 0;
 				cn[i] = fw < rv ? fw : rv;
 				hh[i] = ntsm_fold(cn[i]);
 				const uint32_t bit = ntsm_h1(hh[i]) >> fshift;
-				fwd[i] = p.filter[bit >> 5];                 /* always in range: unconditional, keeps 16 loads in flight */
+				fwd[i] = p.filter[bit >> 5];                 /* always in range: unconditional, keeps 8 loads in flight */
 			}
 #pragma unroll
-			for (int s = 0; s < 4; ++s) {
+			for (int s = 0; s < 2; ++s) {
 				uint4 ba[4], bb[4];
 				bool pos[4];
 #pragma unroll
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 							__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							++nh;
 							if (PER_READ) {
-								const unsigned long long pb = (unsigned long long) (ts + (long long) t * C + 16 * g + i);
+								const unsigned long long pb = (unsigned long long) (ts + (long long) t * C + 8 * g + i);
 								atomicAdd(p.read_hits + ntsm_read_of(p, pb), 1u);
 							}
 						}

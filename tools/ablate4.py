@@ -9,7 +9,7 @@ d_win = torch.from_numpy(s.windows).to(dev)
 d = torch.empty(n * s.stride, dtype=torch.uint8, device=dev)
 s.device_fill(d_win.data_ptr(), 0, n, d.data_ptr()); torch.cuda.synchronize()
 def run(name, env=None):
-    for k in ("NTSM_DEBUG_KERNEL", "NTSM_DEBUG_ZERO_FILTER"): os.environ.pop(k, None)
+    for k in ("NTSM_DEBUG_KERNEL", "NTSM_DEBUG_ZERO_FILTER", "NTSM_PREFILTER_OFF"): os.environ.pop(k, None)
     os.environ.update(env or {})
     ctx = ntsm_amd.Context(sites.keys)
     ctx.count_resident(d.data_ptr(), d.numel(), 0, n); ctx.sync(); ctx.set_timing(True)
@@ -20,4 +20,5 @@ run("full")
 run("push only (drain discards)", {"NTSM_DEBUG_KERNEL": "1"})
 run("push + rebuild + prefilter load, no table", {"NTSM_DEBUG_KERNEL": "2"})
 run("full minus atomics", {"NTSM_DEBUG_KERNEL": "4"})
+run("second-level filter passes everything", {"NTSM_PREFILTER_OFF": "1"})
 run("zero filter (no positives)", {"NTSM_DEBUG_ZERO_FILTER": "1"})
