@@ -115,7 +115,8 @@ int ntsm_reset(ntsm_ctx *ctx);
  * it runs on; get returns the number of launches and the sum of their durations since `on`. */
 int ntsm_set_timing(ntsm_ctx *ctx, int on);
 int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
-/* Tuning knobs (0 = automatic): log2 of filter bits, grid blocks.  For profiling experiments. */
+/* Tuning knobs (0 = automatic): log2 of filter bits (rebuilds the tables: counts and totals restart from zero),
+ * grid blocks.  For profiling experiments. */
 int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
 /* Kernel choice: 0 = automatic (minimizer-blocked fast path when k == 19, generic otherwise),
  * 1 = always the generic kernel.  Both give identical results; for A/B measurements. */

@@ -7,7 +7,8 @@
  *                 the 4 MiB per-XCD L2 (default F = 24 -> 2 MiB): >90 % of read k-mers end here.
  *   keys        : 2-choice cuckoo table, 2^B buckets of two uint64 slots (16 B, one dwordx4 load);
  *                 a site k-mer lives in bucket b1(x) or b2(x); empty slot = ~0.
- *   slot_counts : uint64 per slot, bumped with one no-return 64-bit atomic per hit.
+ *   counters    : uint64 per slot, stored next to their keys (32-byte buckets {key0,key1,count0,count1}), bumped
+ *                 with one no-return 64-bit atomic per hit.
  *   slot_of     : uint32 per site k-mer (dense index -> slot) for the final gather.
  * Keys are the reference's canonical codes (vendor/KseqHashIterator.hpp:99-104); bucket hashes
  * are free to choose because the reference's hash64 is a bijection (results depend only on set
@@ -96,7 +97,6 @@ struct NtsmCountParams {
 	unsigned long long n_tiles;
 	const uint32_t *filter;
 	const uint64_t *keys;
-	unsigned long long *slot_counts;
 	unsigned long long *totals;        /* [0] k-mers, [1] hits */
 	const unsigned long long *read_end;/* per-read attribution (early-stop mode only) */
 	uint32_t *read_hits;

@@ -69,6 +69,14 @@ __device__ __forceinline__ uint4 ntsm_load_vec(const NtsmCountParams &p, long lo
 	return r;
 }
 
+/* Key table layout: 32-byte buckets { key0, key1, count0, count1 } -- the counter of a slot sits in the cache line
+ * its key was just read from, so the atomic of a hit finds the line in L2 instead of costing a second
+ * Infinity-Cache access.  Slot s = 2 * bucket + position. */
+__device__ __forceinline__ unsigned long long *ntsm_count_ptr(const uint64_t *table, long long slot)
+{
+	return const_cast<unsigned long long *>(reinterpret_cast<const unsigned long long *>(table)) + 4 * (slot >> 1) + 2 + (slot & 1);
+}
+
 /* first read whose terminator lies beyond byte offset pos */
 __device__ __forceinline__ unsigned long long ntsm_read_of(const NtsmCountParams &p, unsigned long long pos)
 {
@@ -158,8 +166,8 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 					nk += ok[i] ? 1u : 0u;
 					pos[j] = ok[i] && ((fwd[i] >> ((h1 >> fshift) & 31u)) & 1u);
 					if (pos[j]) {
-						ba[j] = *reinterpret_cast<const uint4 *>(p.keys + 2ull * (h1 >> bshift));
-						bb[j] = *reinterpret_cast<const uint4 *>(p.keys + 2ull * (ntsm_h2(hh[i]) >> bshift));
+						ba[j] = *reinterpret_cast<const uint4 *>(p.keys + 4ull * (h1 >> bshift));
+						bb[j] = *reinterpret_cast<const uint4 *>(p.keys + 4ull * (ntsm_h2(hh[i]) >> bshift));
 					}
 				}
 #pragma unroll
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 						else if (bb[j].x == klo && bb[j].y == khi) slot = (long long) b2;
 						else if (bb[j].z == klo && bb[j].w == khi) slot = (long long) b2 + 1;
 						if (slot >= 0) {
-							__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							__hip_atomic_fetch_add(ntsm_count_ptr(p.keys, slot), p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							++nh;
 							if (PER_READ) {
 								const unsigned long long pb = (unsigned long long) (ts + (long long) t * C + 8 * g + i);
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 #define NTSM_FAST_BRANCHLESS_PUSH 0
 #endif
 #ifndef NTSM_FAST_ASM_LSHLOR
-#define NTSM_FAST_ASM_LSHLOR 0
+#define NTSM_FAST_ASM_LSHLOR 1                        /* one v_lshl_or_b32 for the forward word (hipcc emits shift + or): +1 % */
 #endif
 #if NTSM_FAST_ASM_LSHLOR
 #define NTSM_F_UPDATE(c_) asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(F) : "v"(F), "v"(c_));
@@ -335,13 +343,13 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				else if ((s2_ba.x & s2_ba.y) != 0xFFFFFFFFu && (s2_ba.z & s2_ba.w) != 0xFFFFFFFFu) {
 					/* bucket 1 full and no match: the key can only be in bucket 2 */
 					const unsigned long long b2 = 2ull * (s2_g2 >> bshift);
-					const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + b2);
+					const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + 2ull * b2);
 					if (bb.x == s2_klo && bb.y == s2_khi) slot = (long long) b2;
 					else if (bb.z == s2_klo && bb.w == s2_khi) slot = (long long) b2 + 1;
 				}
 				if (slot >= 0) {
 					if (!(p.debug & 4u))
-						__hip_atomic_fetch_add(p.slot_counts + slot, p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						__hip_atomic_fetch_add(ntsm_count_ptr(p.keys, slot), p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					++nh;
 					if (PER_READ) atomicAdd(p.read_hits + ntsm_read_of(p, (unsigned long long) (ts + (long long) s2_pos)), 1u);
 				}
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			if (s2_v) {
 				s2_klo = s1_klo; s2_khi = s1_khi; s2_g2 = s1_g2; s2_pos = s1_pos;
 				s2_b1 = 2ull * (s1_g1 >> bshift);
-				s2_ba = *reinterpret_cast<const uint4 *>(p.keys + s2_b1);
+				s2_ba = *reinterpret_cast<const uint4 *>(p.keys + 2ull * s2_b1);
 			}
 			/* stage 1 */
 			s1_v = false;
@@ -499,12 +507,19 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 	}
 }
 
-/* dense[i] = slot_counts[slot_of[i]]; tail = totals */
-__global__ void ntsm_gather_kernel(const unsigned long long *slot_counts, const uint32_t *slot_of,
-		uint32_t n, unsigned long long *dense)
+/* dense[i] = count of slot_of[i]; tail = totals */
+__global__ void ntsm_gather_kernel(const uint64_t *table, const uint32_t *slot_of, uint32_t n, unsigned long long *dense)
 {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-		dense[i] = slot_counts[slot_of[i]];
+		dense[i] = *ntsm_count_ptr(table, (long long) slot_of[i]);
+}
+
+__global__ void ntsm_zero_counts_kernel(uint64_t *table, unsigned long long n_buckets)
+{
+	for (unsigned long long b = blockIdx.x * (unsigned long long) blockDim.x + threadIdx.x; b < n_buckets; b += (unsigned long long) gridDim.x * blockDim.x) {
+		table[4 * b + 2] = 0;
+		table[4 * b + 3] = 0;
+	}
 }
 
 } // namespace
@@ -575,7 +590,7 @@ struct ntsm_ctx {
 	uint32_t *d_filter = nullptr, *d_slot_of = nullptr, *d_read_hits = nullptr;
 	uint64_t read_hits_cap = 0;
 	uint64_t *d_keys = nullptr;
-	unsigned long long *d_slot_counts = nullptr, *d_totals = nullptr, *d_vec = nullptr;
+	unsigned long long *d_totals = nullptr, *d_vec = nullptr;
 	uint8_t *d_lut = nullptr;
 	uint2 *d_lut64 = nullptr;
 	uint32_t filter_log2 = 0, bucket_log2 = 0;
@@ -748,16 +763,17 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	}
 	if (c->d_filter) (void) hipFree(c->d_filter);
 	if (c->d_keys) (void) hipFree(c->d_keys);
-	if (c->d_slot_counts) (void) hipFree(c->d_slot_counts);
 	if (c->d_slot_of) (void) hipFree(c->d_slot_of);
-	c->d_filter = nullptr; c->d_keys = nullptr; c->d_slot_counts = nullptr; c->d_slot_of = nullptr;
+	c->d_filter = nullptr; c->d_keys = nullptr; c->d_slot_of = nullptr;
 	HIPCHK(hipMalloc(&c->d_filter, filter.size() * sizeof(uint32_t)));
-	HIPCHK(hipMalloc(&c->d_keys, c->n_slots * sizeof(uint64_t)));
-	HIPCHK(hipMalloc(&c->d_slot_counts, c->n_slots * sizeof(uint64_t)));
+	HIPCHK(hipMalloc(&c->d_keys, 2 * c->n_slots * sizeof(uint64_t)));   /* { key0, key1, count0, count1 } per bucket */
 	HIPCHK(hipMalloc(&c->d_slot_of, (n ? n : 1) * sizeof(uint32_t)));
 	HIPCHK(hipMemcpy(c->d_filter, filter.data(), filter.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(c->d_keys, keys.data(), c->n_slots * sizeof(uint64_t), hipMemcpyHostToDevice));
-	HIPCHK(hipMemset(c->d_slot_counts, 0, c->n_slots * sizeof(uint64_t)));
+	{
+		std::vector<uint64_t> table(2 * c->n_slots, 0);
+		for (uint64_t b = 0; b < c->n_slots / 2; ++b) { table[4 * b] = keys[2 * b]; table[4 * b + 1] = keys[2 * b + 1]; }
+		HIPCHK(hipMemcpy(c->d_keys, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+	}
 	if (n) HIPCHK(hipMemcpy(c->d_slot_of, c->slot_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIPCHK(hipDeviceSynchronize());                      /* tables and zeroed counters visible before any stream uses them */
 	return NTSM_OK;
@@ -801,7 +817,6 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.n_tiles = (hi - (uint64_t) p.t0 + tile - 1) / tile;
 	p.filter = c->d_filter;
 	p.keys = c->d_keys;
-	p.slot_counts = c->d_slot_counts;
 	p.totals = c->d_totals;
 	p.read_end = (const unsigned long long *) d_read_end;
 	p.read_hits = c->d_read_hits;
@@ -1090,7 +1105,7 @@ void ntsm_destroy(ntsm_ctx *c)
 		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
 		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
 	}
-	void *ptrs[] = { c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_counts, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
+	void *ptrs[] = { c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
 	for (void *p : ptrs) if (p) (void) hipFree(p);
 	delete c;
 }
@@ -1221,7 +1236,7 @@ int ntsm_counts_device(ntsm_ctx *c, void **d_vec, uint64_t *n_words)
 	if (rc) return rc;
 	if (!c->reduced) {
 		if (c->n_kmers) {
-			hipLaunchKernelGGL(ntsm_gather_kernel, dim3(1024), dim3(256), 0, c->rstream, c->d_slot_counts, c->d_slot_of, c->n_kmers, c->d_vec);
+			hipLaunchKernelGGL(ntsm_gather_kernel, dim3(1024), dim3(256), 0, c->rstream, c->d_keys, c->d_slot_of, c->n_kmers, c->d_vec);
 			HIPCHK(hipGetLastError());
 		}
 		const uint64_t tail[4] = { t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed };
@@ -1259,7 +1274,8 @@ int ntsm_reset(ntsm_ctx *c)
 	if (rc) return rc;
 	/* on the context's own stream and waited for: a null-stream memset is not ordered against the
 	 * non-blocking streams the count kernels run on */
-	HIPCHK(hipMemsetAsync(c->d_slot_counts, 0, c->n_slots * sizeof(uint64_t), c->rstream));
+	hipLaunchKernelGGL(ntsm_zero_counts_kernel, dim3(1024), dim3(256), 0, c->rstream, c->d_keys, (unsigned long long) (c->n_slots / 2));
+	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemsetAsync(c->d_totals, 0, 4 * sizeof(uint64_t), c->rstream));
 	HIPCHK(hipStreamSynchronize(c->rstream));
 	c->total_bases = c->reads_consumed = 0;
@@ -1304,15 +1320,12 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 	if (rc) return rc;
 	c->grid_blocks = grid_blocks;
 	if (filter_log2_bits > 0) {
-		/* counts are slot-indexed: keep them across the rebuild only if the table is untouched */
-		std::vector<uint64_t> saved(c->n_slots);
-		HIPCHK(hipMemcpy(saved.data(), c->d_slot_counts, c->n_slots * sizeof(uint64_t), hipMemcpyDeviceToHost));
-		const uint64_t old_slots = c->n_slots;
-		const std::vector<uint32_t> old_slot_of = c->slot_of;
-		rc = build_tables(c, filter_log2_bits);
+		rc = build_tables(c, filter_log2_bits);              /* rebuilds filters and table: counts start from zero again */
 		if (rc) return rc;
-		if (c->n_slots == old_slots && c->slot_of == old_slot_of)
-			HIPCHK(hipMemcpy(c->d_slot_counts, saved.data(), c->n_slots * sizeof(uint64_t), hipMemcpyHostToDevice));
+		HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
+		HIPCHK(hipDeviceSynchronize());
+		c->total_bases = c->reads_consumed = 0;
+		c->early_stop = c->reduced = false;
 	}
 	return NTSM_OK;
 }

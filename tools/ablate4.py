@@ -17,8 +17,15 @@ def run(name, env=None):
     t = ctx.sync(); k, ms = ctx.get_timing()
     print(json.dumps({"case": name, "ms": round(ms / k, 2), "gbases_s": round(n * 150 / (ms / k) / 1e6, 1), "hits": t.total_hits // 4})); ctx.close()
 run("full")
+run_tiny = True
 run("push only (drain discards)", {"NTSM_DEBUG_KERNEL": "1"})
 run("push + rebuild + prefilter load, no table", {"NTSM_DEBUG_KERNEL": "2"})
 run("full minus atomics", {"NTSM_DEBUG_KERNEL": "4"})
 run("second-level filter passes everything", {"NTSM_PREFILTER_OFF": "1"})
 run("zero filter (no positives)", {"NTSM_DEBUG_ZERO_FILTER": "1"})
+
+ctx = ntsm_amd.Context(sites.keys[:16])
+ctx.count_resident(d.data_ptr(), d.numel(), 0, n); ctx.sync(); ctx.set_timing(True)
+for _ in range(3): ctx.count_resident(d.data_ptr(), d.numel(), 0, n)
+ctx.sync(); k, ms = ctx.get_timing()
+print(json.dumps({"case": "16-key site set (compute floor)", "ms": round(ms / k, 2), "gbases_s": round(n * 150 / (ms / k) / 1e6, 1)})); ctx.close()
