@@ -90,6 +90,32 @@ int ntsm_submit_staged(ntsm_ctx *ctx, uint64_t n_bytes, uint32_t n_reads);
 /* Resize the two staging slots (default 64 MiB of bases, 1 Mi reads each). */
 int ntsm_set_batch_capacity(ntsm_ctx *ctx, uint64_t cap_bytes, uint64_t cap_reads);
 
+/* Producer lanes: SEVERAL host threads feeding ONE context -- the reference's `omp parallel for` over files with a
+ * shared m_counts and `#pragma omp atomic` increments (src/FingerPrint.hpp:47, :94-99).  A lane is one thread's
+ * private pair of pinned staging slots (cap_bytes of bases / cap_reads offsets each; 0 = the context's defaults)
+ * with their own streams; every lane counts into the context's tables.  Calls on different lanes may run
+ * concurrently; one lane is driven by one thread.  acquire/submit behave like ntsm_staging_acquire /
+ * ntsm_submit_staged.  close drains the lane and folds its totals into the context; ntsm_sync, ntsm_counts*,
+ * ntsm_reset and ntsm_set_tuning return NTSM_ERR_STATE while a lane is open.  Lanes are refused
+ * (NTSM_ERR_STATE) on a context with max_hits != 0: the -m stop is defined on one ordered stream of reads. */
+typedef struct ntsm_lane ntsm_lane;
+int ntsm_lane_open(ntsm_ctx *ctx, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lane **out);
+int ntsm_lane_acquire(ntsm_lane *lane, uint8_t **bases, uint64_t *cap_bytes, uint64_t **read_end,
+		uint64_t *cap_reads);
+int ntsm_lane_submit(ntsm_lane *lane, uint64_t n_bytes, uint32_t n_reads);
+int ntsm_lane_close(ntsm_lane *lane);
+
+/* Initialise the HIP runtime and the device context of `device` (idempotent, thread-safe): lets a host overlap
+ * the ~0.3 s of GPU bring-up with loading the sites file (src/FingerPrint.hpp:489-572) before ntsm_create. */
+int ntsm_warmup(int device);
+
+/* Reserve a process-wide pool of `bytes` of pinned host memory that contexts and lanes carve their staging slots
+ * from (they fall back to individual allocations when it is exhausted).  Pinning costs ~0.4 ms/MiB and the driver
+ * serialises it, so a host calls this once, early and off its critical path (ntsmCount: on a side thread while the
+ * sites file is parsed).  A second call succeeds if the pool is already at least that large.  bytes = 0 releases
+ * the pool (NTSM_ERR_STATE while slots are still taken from it); otherwise it lives until the process ends. */
+int ntsm_staging_pool(uint64_t bytes);
+
 /* Count a batch already RESIDENT in device memory (d_bases 16-byte aligned).  d_read_end may be
  * NULL when the context has no early stop armed (max_hits == 0).  sign = +1 counts, -1 removes
  * the batch's contribution again (exact: integer adds).  Asynchronous on the context's stream. */

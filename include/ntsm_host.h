@@ -36,6 +36,13 @@ uint64_t ntsm_host_max_hits(uint64_t n_distinct, double cov_thresh);
 int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint64_t **read_end,
 		uint64_t *n_reads, int *last_rc);
 void ntsm_host_free(void *p);
+/* Block-parallel variant for plain 4-line FASTQ (ntsm_amd/csrc/host/parallel_fastq.hpp), for tests: the records
+ * the parallel phase commits (in file order) followed by what the sequential reader yields from *resume on.
+ * Returns 0, 1 if the file is not eligible (callers use ntsm_host_flatten), -1 if it cannot be opened.
+ * *n_parallel = records parsed by the parallel phase; *resume = byte offset it stopped at (file size if complete). */
+int ntsm_host_flatten_parallel(const char *path, unsigned n_threads, uint64_t block_bytes, uint8_t **bases,
+		uint64_t *n_bytes, uint64_t **read_end, uint64_t *n_reads, uint64_t *n_blocks, uint64_t *n_parallel,
+		uint64_t *resume);
 
 /* counts.txt bytes for per-k-mer counts in key order.  Returns 0, or 1 if the reference would
  * abort while printing (then *out holds the rows written before the abort). */

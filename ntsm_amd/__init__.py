@@ -5,8 +5,8 @@ ntsm_amd/libntsm_host.so (host reader / site loader / report formatting) and bui
 This package is only the ctypes plumbing tests and bench.py use; importing it fails loudly when the
 HIP library has not been built (there is no CPU fallback)."""
 from . import capi
-from .capi import (Context, Sites, SynthLong, SynthShort, flatten_file, hash64, hash64_inv, hip_lib, host_lib,
-                   max_hits_for, synth_lib, NtsmError)
+from .capi import (Context, Lane, Sites, SynthLong, SynthShort, flatten_file, hash64, hash64_inv, hip_lib, host_lib,
+                   max_hits_for, synth_lib, warmup, staging_pool, NtsmError)
 
-__all__ = ["capi", "Context", "Sites", "SynthShort", "SynthLong", "flatten_file", "hash64", "hash64_inv", "hip_lib",
+__all__ = ["capi", "Context", "Lane", "warmup", "staging_pool", "Sites", "SynthShort", "SynthLong", "flatten_file", "hash64", "hash64_inv", "hip_lib",
            "host_lib", "synth_lib", "max_hits_for", "NtsmError"]

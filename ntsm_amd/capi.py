@@ -59,6 +59,12 @@ _sig(H, "ntsm_submit", C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, C.c_uint32])
 _sig(H, "ntsm_staging_acquire", C.c_int, [C.c_void_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p])
 _sig(H, "ntsm_submit_staged", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32])
 _sig(H, "ntsm_set_batch_capacity", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64])
+_sig(H, "ntsm_lane_open", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)])
+_sig(H, "ntsm_lane_acquire", C.c_int, [C.c_void_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p])
+_sig(H, "ntsm_lane_submit", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32])
+_sig(H, "ntsm_lane_close", C.c_int, [C.c_void_p])
+_sig(H, "ntsm_warmup", C.c_int, [C.c_int])
+_sig(H, "ntsm_staging_pool", C.c_int, [C.c_uint64])
 _sig(H, "ntsm_count_resident", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int])
 _sig(H, "ntsm_sync", C.c_int, [C.c_void_p, C.POINTER(Totals)])
 _sig(H, "ntsm_counts", C.c_int, [C.c_void_p, u64p])
@@ -87,6 +93,7 @@ _sig(HO, "ntsm_sites_n_erased", C.c_uint64, [C.c_void_p])
 _sig(HO, "ntsm_host_max_hits", C.c_uint64, [C.c_uint64, C.c_double])
 _sig(HO, "ntsm_host_flatten", C.c_int, [C.c_char_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, C.POINTER(C.c_int)])
 _sig(HO, "ntsm_host_free", None, [C.c_void_p])
+_sig(HO, "ntsm_host_flatten_parallel", C.c_int, [C.c_char_p, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, u64p])
 _sig(HO, "ntsm_host_format_counts", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)])
 _sig(HO, "ntsm_host_format_summary", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), u64p])
@@ -180,6 +187,24 @@ def flatten_file(path):
     return bases, ends, rc.value
 
 
+def flatten_file_parallel(path, n_threads=4, block_bytes=1 << 20):
+    """Block-parallel plain-FASTQ parse (+ sequential tail); None when the file is not eligible (use flatten_file).
+    Returns (bases, read_end, info) with info = dict(blocks, parallel_records, resume)."""
+    b, e = u8p(), u64p()
+    nb, nr, nblk, npar, res = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = HO.ntsm_host_flatten_parallel(os.fsencode(path), n_threads, block_bytes, C.byref(b), C.byref(nb), C.byref(e), C.byref(nr),
+                                       C.byref(nblk), C.byref(npar), C.byref(res))
+    if rc < 0:
+        raise NtsmError("flatten_parallel(%s) failed: %d" % (path, rc))
+    if rc == 1:
+        return None
+    bases = np.ctypeslib.as_array(b, shape=(nb.value,)).copy() if nb.value else np.zeros(0, np.uint8)
+    ends = np.ctypeslib.as_array(e, shape=(nr.value,)).copy() if nr.value else np.zeros(0, np.uint64)
+    HO.ntsm_host_free(b)
+    HO.ntsm_host_free(e)
+    return bases, ends, dict(blocks=int(nblk.value), parallel_records=int(npar.value), resume=int(res.value))
+
+
 def flatten_reads(reads):
     """Flat-stream layout from a list of bytes objects."""
     parts, ends, off = [], [], 0
@@ -205,6 +230,10 @@ class Context:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         read_end = np.ascontiguousarray(read_end, dtype=np.uint64)
         _chk(H.ntsm_submit(self._h, _p(bases, u8p), bases.size, _p(read_end, u64p), read_end.size), "ntsm_submit")
+
+    def open_lane(self, cap_bytes=0, cap_reads=0):
+        """A producer lane (ntsm_lane_*): one host thread's private staging into this context."""
+        return Lane(self, cap_bytes, cap_reads)
 
     def set_batch_capacity(self, cap_bytes, cap_reads):
         _chk(H.ntsm_set_batch_capacity(self._h, cap_bytes, cap_reads), "ntsm_set_batch_capacity")
@@ -262,6 +291,46 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class Lane:
+    def __init__(self, ctx, cap_bytes=0, cap_reads=0):
+        self._h = C.c_void_p()
+        self._ctx = ctx                                   # keeps the context alive
+        _chk(H.ntsm_lane_open(ctx._h, cap_bytes, cap_reads, C.byref(self._h)), "ntsm_lane_open")
+
+    def submit(self, bases, read_end):
+        """acquire + copy + submit; the batch must fit the lane's slot."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_end = np.ascontiguousarray(read_end, dtype=np.uint64)
+        hb, hr = u8p(), u64p()
+        cb, cr = C.c_uint64(), C.c_uint64()
+        _chk(H.ntsm_lane_acquire(self._h, C.byref(hb), C.byref(cb), C.byref(hr), C.byref(cr)), "ntsm_lane_acquire")
+        if bases.size > cb.value or read_end.size > cr.value:
+            _chk(H.ntsm_lane_submit(self._h, 0, 0), "ntsm_lane_submit")     # give the slot back
+            raise NtsmError("batch larger than the lane's slot")
+        C.memmove(hb, bases.ctypes.data, bases.size)
+        C.memmove(hr, read_end.ctypes.data, read_end.size * 8)
+        _chk(H.ntsm_lane_submit(self._h, bases.size, read_end.size), "ntsm_lane_submit")
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, C.c_void_p()
+            _chk(H.ntsm_lane_close(h), "ntsm_lane_close")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def warmup(device=0):
+    _chk(H.ntsm_warmup(device), "ntsm_warmup")
+
+
+def staging_pool(n_bytes):
+    _chk(H.ntsm_staging_pool(n_bytes), "ntsm_staging_pool")
 
 
 class SynthShort:

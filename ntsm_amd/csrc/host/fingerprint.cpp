@@ -10,6 +10,8 @@
 #include <sstream>
 #include <thread>
 
+#include "parallel_fastq.hpp"
+#include <chrono>
 #include "report.hpp"
 #include "seq_reader.hpp"
 
@@ -36,24 +38,43 @@ void Feeder::die(int rc, const char *what) const
 }
 
 static std::mutex g_stderr;
+static constexpr uint64_t kLaneBytes = 16ull << 20;     /* staging slot of a producer lane (-t N) */
 
-Feeder::Feeder(const Options &opt, const SiteSet &sites, uint64_t max_hits, int device) : m_opt(opt), m_maxCounts(max_hits)
+Feeder::Feeder(const Options &opt, ntsm_ctx *ctx, uint64_t max_hits, bool lane) : m_opt(opt), m_ctx(ctx), m_useLane(lane), m_maxCounts(max_hits)
 {
-	if (sites.keys.size() > 0xFFFFFFFFull) die(NTSM_ERR_ARG, "too many site k-mers");
-	int rc = ntsm_create(&m_ctx, device, (int) m_opt.k, sites.keys.data(), (uint32_t) sites.keys.size(),
-			NTSM_KEYS_CANONICAL, m_maxCounts);
-	if (rc) die(rc, "cannot create GPU context");
 	m_cfgBytes = m_opt.batch_bytes < 4096 ? 4096 : m_opt.batch_bytes;
-	rc = ntsm_set_batch_capacity(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16);
-	if (rc) die(rc, "cannot size staging buffers");
+	if (m_useLane) {
+		/* N producers share the GPU: smaller slots keep the pinned footprint (and its allocation time) flat */
+		m_cfgBytes = std::max<uint64_t>(4096, std::min<uint64_t>(m_cfgBytes, kLaneBytes));
+		openLane();
+	} else {
+		int rc = ntsm_set_batch_capacity(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16);
+		if (rc) die(rc, "cannot size staging buffers");
+	}
 }
 
-Feeder::~Feeder() { ntsm_destroy(m_ctx); }
+void Feeder::openLane()
+{
+	int rc = ntsm_lane_open(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16, &m_lane);
+	if (rc) die(rc, "cannot open a producer lane");
+}
+
+Feeder::~Feeder() { if (m_lane) ntsm_lane_close(m_lane); }
+
+void Feeder::finish()
+{
+	flush();
+	if (m_lane) {
+		int rc = ntsm_lane_close(m_lane);
+		m_lane = nullptr;
+		if (rc) die(rc, "cannot close a producer lane");
+	}
+}
 
 void Feeder::flush()
 {
-	if (!m_bases) return;
-	int rc = ntsm_submit_staged(m_ctx, m_fill, m_nReads);
+	if (!m_bases || m_nReads == 0) return;
+	int rc = m_useLane ? ntsm_lane_submit(m_lane, m_fill, m_nReads) : ntsm_submit_staged(m_ctx, m_fill, m_nReads);
 	if (rc) die(rc, "submit failed");
 	m_bases = nullptr;
 	m_fill = 0;
@@ -72,98 +93,218 @@ void Feeder::flush()
 	}
 }
 
-void Feeder::feedFile(const std::string &fn)
+void Feeder::feedFile(const std::string &fn, uint64_t offset)
 {
 	SeqReader rd;
-	if (!rd.open(fn)) {
+	if (!rd.open(fn, offset)) {
 		std::lock_guard<std::mutex> lk(g_stderr);
 		std::cerr << "file " << fn << " cannot be opened" << std::endl;
 		exit(1);
-	} else if (m_opt.verbose) {
+	} else if (m_opt.verbose && offset == 0) {
 		std::lock_guard<std::mutex> lk(g_stderr);
 		std::cerr << "Opening " << fn << std::endl;
 	}
 	int64_t l = rd.next();
 	while (l >= 0 && !m_earlyTerm) {
-		const uint64_t len = (uint64_t) l;
-		if (m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)) flush();
-		if (m_earlyTerm) break;
-		if (!m_bases) {
-			if (len + 1 > m_cfgBytes) {                              /* a read longer than a slot: grow both slots */
-				m_cfgBytes = (len + 1) + (len + 1) / 2;
-				int rc = ntsm_set_batch_capacity(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16);
-				if (rc) die(rc, "cannot grow staging buffers");
-			}
-			int rc = ntsm_staging_acquire(m_ctx, &m_bases, &m_capBytes, &m_readEnd, &m_capReads);
-			if (rc) die(rc, "cannot acquire staging");
-		}
-		memcpy(m_bases + m_fill, rd.seq_data(), len);
-		m_fill += len;
-		m_bases[m_fill] = 'N';                               /* read terminator */
-		m_readEnd[m_nReads++] = m_fill;
-		m_fill += 1;
+		feedRead(rd.seq_data(), (uint64_t) l);
 		l = rd.next();
 	}
 }
 
+void Feeder::feedRead(const char *seq, uint64_t len)
+{
+	if (m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)) flush();
+	if (m_earlyTerm) return;
+	if (!m_bases) {
+		if (len + 1 > m_cfgBytes) {                              /* a read longer than a slot: grow both slots */
+			m_cfgBytes = (len + 1) + (len + 1) / 2;
+			if (m_useLane) {
+				int rc = ntsm_lane_close(m_lane);
+				m_lane = nullptr;
+				if (rc) die(rc, "cannot grow staging buffers");
+				openLane();
+			} else {
+				int rc = ntsm_set_batch_capacity(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16);
+				if (rc) die(rc, "cannot grow staging buffers");
+			}
+		}
+		int rc = m_useLane ? ntsm_lane_acquire(m_lane, &m_bases, &m_capBytes, &m_readEnd, &m_capReads)
+		                   : ntsm_staging_acquire(m_ctx, &m_bases, &m_capBytes, &m_readEnd, &m_capReads);
+		if (rc) die(rc, "cannot acquire staging");
+	}
+	memcpy(m_bases + m_fill, seq, len);
+	m_fill += len;
+	m_bases[m_fill] = 'N';                               /* read terminator */
+	m_readEnd[m_nReads++] = m_fill;
+	m_fill += 1;
+}
+
 FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 {
-	if (!m_sites.load(m_opt.snp, m_opt.k, m_opt.dupes, std::cerr)) {
+	if (m_opt.devices.empty()) m_opt.devices.push_back(m_opt.device);
+	for (int d : m_opt.devices)
+		if (std::find(m_ctxDevice.begin(), m_ctxDevice.end(), d) == m_ctxDevice.end()) m_ctxDevice.push_back(d);
+	/* GPU bring-up (runtime + device context, ~0.3 s) and the pinning of all staging memory run while this thread
+	 * parses the sites file; the pool is only needed when the first batch is staged (computeCounts). */
+	const auto tc0 = std::chrono::steady_clock::now();
+	std::vector<std::thread> warm;
+	for (int d : m_ctxDevice) warm.emplace_back([d]() { (void) ntsm_warmup(d); });
+	{
+		const bool maybe_armed = m_opt.covThresh != 0 && m_opt.covThresh < 1e300;
+		const uint64_t slot = std::max<uint64_t>(4096, m_opt.batch_bytes);
+		uint64_t bytes;
+		if (m_opt.threads > 1 && !maybe_armed) bytes = (uint64_t) m_opt.threads * 2 * (std::min<uint64_t>(slot, kLaneBytes) + 8192);
+		else bytes = 2 * (slot + 8192 + (slot / 64 + 16) * 8 + 8192);
+		const int d0 = m_ctxDevice[0];
+		m_poolThread = std::thread([d0, bytes]() { if (ntsm_warmup(d0) == NTSM_OK) (void) ntsm_staging_pool(bytes); });
+	}
+	const bool loaded = m_sites.load(m_opt.snp, m_opt.k, m_opt.dupes, std::cerr);
+	const auto tc1 = std::chrono::steady_clock::now();
+	for (auto &w : warm) w.join();
+	const auto tc2 = std::chrono::steady_clock::now();
+	if (!loaded) {
 		std::cerr << "file " << m_opt.snp << " cannot be opened" << std::endl;   /* :493-499 */
 		exit(1);
 	}
 	if (m_opt.verbose) std::cerr << "Opening " << m_opt.snp << std::endl;
 	m_maxCounts = threshold_from((double) m_sites.n_distinct(), m_opt.covThresh);
-	if (m_opt.devices.empty()) m_opt.devices.push_back(m_opt.device);
-	m_feeders.emplace_back(new Feeder(m_opt, m_sites, m_maxCounts, m_opt.devices[0]));
+	if (m_sites.keys.size() > 0xFFFFFFFFull) {
+		std::cerr << "ntsmCount: too many site k-mers" << std::endl;
+		exit(1);
+	}
+	/* one context per distinct device; with -m everything runs on the first one */
+	if (m_maxCounts != 0) m_ctxDevice.resize(1);
+	m_ctx.assign(m_ctxDevice.size(), nullptr);
+	std::vector<int> rcs(m_ctxDevice.size(), 0);
+	std::vector<std::thread> mk;
+	for (size_t i = 0; i < m_ctxDevice.size(); ++i)
+		mk.emplace_back([&, i]() {
+			rcs[i] = ntsm_create(&m_ctx[i], m_ctxDevice[i], (int) m_opt.k, m_sites.keys.data(), (uint32_t) m_sites.keys.size(),
+					NTSM_KEYS_CANONICAL, m_maxCounts);
+		});
+	for (auto &t : mk) t.join();
+	if (m_opt.phase_times)
+		std::cerr << "[phase] sites parsed " << std::chrono::duration<double>(tc1 - tc0).count() << " s, +GPU bring-up wait "
+		          << std::chrono::duration<double>(tc2 - tc1).count() << " s, contexts (tables + upload) "
+		          << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc2).count() << " s" << std::endl;
+	for (size_t i = 0; i < rcs.size(); ++i)
+		if (rcs[i]) {
+			std::cerr << "ntsmCount: cannot create GPU context: " << ntsm_strerror(rcs[i]);
+			if (rcs[i] == NTSM_ERR_HIP) std::cerr << " (hipError " << ntsm_last_hip_error() << ")";
+			std::cerr << std::endl;
+			exit(1);
+		}
 }
 
-FingerPrint::~FingerPrint() { }
+FingerPrint::~FingerPrint()
+{
+	if (m_poolThread.joinable()) m_poolThread.join();
+	m_main.reset();
+	m_lanes.clear();
+	for (ntsm_ctx *c : m_ctx) ntsm_destroy(c);
+}
+
+Feeder &FingerPrint::feederFor(size_t t)
+{
+	if (!m_lanes[t]) {
+		const int dev = m_opt.devices[t % m_opt.devices.size()];
+		const size_t ci = (size_t) (std::find(m_ctxDevice.begin(), m_ctxDevice.end(), dev) - m_ctxDevice.begin());
+		m_lanes[t].reset(new Feeder(m_opt, m_ctx[ci], 0, true));
+	}
+	return *m_lanes[t];
+}
+
+void FingerPrint::closeLanes()
+{
+	for (auto &f : m_lanes) if (f) f->finish();
+	m_lanes.clear();
+}
 
 void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 {
-	/* The reference runs this loop under `omp parallel for` over files (:47): -t N means N files at a time.
-	 * Same here when no -m threshold is armed: N host threads, each with its own GPU context on the same
-	 * device, pull files from a shared index; per-k-mer counts are summed afterwards (order cannot matter).
+	/* The reference runs this loop under `omp parallel for` over files (:47) with ONE shared m_counts and atomic
+	 * increments: -t N means N files at a time.  Same here when no -m threshold is armed: N host threads, each
+	 * with its own producer lane (pinned staging + stream) of the SAME GPU context, pull work from a shared
+	 * index; the counts meet in the context's table (one context per device with -g a,b: summed at the end).
 	 * With -m the reference's parallel schedule is a race; the only defined semantics is
 	 * argv order on one thread, which is what an armed run always uses. */
-	const size_t n_threads = m_maxCounts != 0 ? 1 : std::min<size_t>(std::max(1u, m_opt.threads), filenames.size());
-	if (n_threads <= 1) {
-		Feeder &f = *m_feeders[0];
+	const size_t want = m_maxCounts != 0 ? 1 : std::max(1u, m_opt.threads);
+	if (m_poolThread.joinable()) {
+		const auto tj = std::chrono::steady_clock::now();
+		m_poolThread.join();
+		if (m_opt.phase_times) std::cerr << "[phase] waited " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tj).count() << " s for the pinned pool" << std::endl;
+	}
+	if (want <= 1) {
+		if (!m_main) m_main.reset(new Feeder(m_opt, m_ctx[0], m_maxCounts, false));
+		Feeder &f = *m_main;
 		for (const std::string &fn : filenames) f.feedFile(fn);    /* after a stop: still opened, nothing counted (:66) */
 		f.flush();
 		if (f.earlyTerm()) std::cerr << "Reached desired (-m) threshold" << std::endl;   /* :84-86 */
 		return;
 	}
-	m_feeders.resize(n_threads);
-	std::atomic<size_t> next(0);
-	std::vector<std::thread> pool;
-	for (size_t t = 0; t < n_threads; ++t)
-		pool.emplace_back([&, t]() {
-			if (!m_feeders[t])                                  /* contexts are built in parallel too, spread over the -g devices */
-				m_feeders[t].reset(new Feeder(m_opt, m_sites, 0, m_opt.devices[t % m_opt.devices.size()]));
-			Feeder &f = *m_feeders[t];
-			for (size_t i = next++; i < filenames.size(); i = next++) f.feedFile(filenames[i]);
-			f.flush();
-		});
-	for (auto &th : pool) th.join();
+	m_lanes.resize(want);
+	/* Big plain FASTQ files are cut into blocks and parsed by all threads (parallel_fastq.hpp); files that are not
+	 * eligible (gzip, FASTA, wrapped or CR lines, small) are taken whole, one thread per file. */
+	std::vector<std::string> rest;
+	for (const std::string &fn : filenames) {
+		ParallelFastq pf;
+		if (!pf.open(fn, m_opt.block_bytes)) { rest.push_back(fn); continue; }
+		const auto tp0 = std::chrono::steady_clock::now();
+		if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "block-parallel: " << pf.n_blocks() << " blocks, " << want << " threads" << std::endl;
+		std::vector<Feeder *> sinks;
+		{
+			std::vector<std::thread> mk;                         /* lanes (pinned staging) are allocated in parallel */
+			for (size_t t = 0; t < want; ++t) mk.emplace_back([this, t]() { (void) feederFor(t); });
+			for (auto &th : mk) th.join();
+		}
+		for (size_t t = 0; t < want; ++t) sinks.push_back(&feederFor(t));
+		const auto tp1 = std::chrono::steady_clock::now();
+		const ParallelFastq::Result r = pf.run(sinks);
+		const auto tp2 = std::chrono::steady_clock::now();
+		if (!r.complete) {                                      /* the rest of the file is not plain 4-line FASTQ */
+			if (m_opt.verbose) std::cerr << "block-parallel: sequential from byte " << r.resume << std::endl;
+			feederFor(0).feedFile(fn, r.resume);
+			feederFor(0).flush();
+		}
+		if (m_opt.phase_times)
+			std::cerr << "[phase] " << fn << ": lanes " << std::chrono::duration<double>(tp1 - tp0).count() << " s, parse+count "
+			          << std::chrono::duration<double>(tp2 - tp1).count() << " s (" << r.records << " records in parallel)" << std::endl;
+	}
+	if (!rest.empty()) {
+		const size_t n_threads = std::min<size_t>(want, rest.size());
+		std::atomic<size_t> next(0);
+		std::vector<std::thread> pool;
+		for (size_t t = 0; t < n_threads; ++t)
+			pool.emplace_back([&, t]() {
+				Feeder &f = feederFor(t);
+				for (size_t i = next++; i < rest.size(); i = next++) f.feedFile(rest[i]);
+				f.flush();
+			});
+		for (auto &th : pool) th.join();
+	}
+	const auto tc0 = std::chrono::steady_clock::now();
+	closeLanes();
+	if (m_opt.phase_times) std::cerr << "[phase] lanes closed in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count() << " s" << std::endl;
 }
 
 void FingerPrint::fetchResults()
 {
 	if (m_fetched) return;
+	m_main.reset();
+	closeLanes();
 	m_counts.assign(m_sites.keys.size(), 0);
 	m_totals = ntsm_totals();
 	std::vector<uint64_t> part(m_sites.keys.size());
-	for (auto &f : m_feeders) {
+	for (ntsm_ctx *c : m_ctx) {
 		ntsm_totals t;
-		int rc = ntsm_sync(f->ctx(), &t);
-		if (rc == 0) rc = ntsm_counts(f->ctx(), part.data());
+		int rc = ntsm_sync(c, &t);
+		if (rc == 0) rc = ntsm_counts(c, m_ctx.size() == 1 ? m_counts.data() : part.data());
 		if (rc) {
 			std::cerr << "ntsmCount: cannot fetch counts: " << ntsm_strerror(rc) << std::endl;
 			exit(1);
 		}
-		for (size_t i = 0; i < part.size(); ++i) m_counts[i] += part[i];
+		if (m_ctx.size() > 1)
+			for (size_t i = 0; i < part.size(); ++i) m_counts[i] += part[i];
 		m_totals.total_kmers += t.total_kmers;
 		m_totals.total_hits += t.total_hits;
 		m_totals.total_bases += t.total_bases;

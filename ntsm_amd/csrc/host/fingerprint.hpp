@@ -10,6 +10,7 @@
 #include <iosfwd>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/ntsm_hip.h"
@@ -28,25 +29,41 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	int device = 0;                        /* HIP device (new; the reference has no device concept) */
 	std::vector<int> devices;              /* -g 0,1,...: host threads (-t) are spread round-robin over these devices */
 	uint64_t batch_bytes = 64ull << 20;    /* staging capacity per slot */
+	bool phase_times = false;              /* NTSM_PHASE_TIMES: print where the wall time goes (stderr) */
+	/* Block size of the block-parallel FASTQ ingest (-t N, plain files).  A block's sequences (< half its bytes) fit
+	 * one 16 MiB lane slot, so a thread never has to wait for its predecessor in the middle of a block. */
+	uint64_t block_bytes = 16ull << 20;
 };
 
-/* One GPU context plus the staging batch being filled for it.  A Feeder is driven by one thread. */
+/* The staging batch one host thread is filling for a GPU context: the context's own slots (single-threaded and
+ * -m runs) or a producer lane of it (-t N: all threads count into the same context).  Driven by one thread. */
 class Feeder {
 public:
-	Feeder(const Options &opt, const SiteSet &sites, uint64_t max_hits, int device);
+	Feeder(const Options &opt, ntsm_ctx *ctx, uint64_t max_hits, bool lane);
 	~Feeder();
 	Feeder(const Feeder &) = delete;
 	Feeder &operator=(const Feeder &) = delete;
 	/* Count every record of one file (src/FingerPrint.hpp:49-81); stops early once the -m threshold tripped. */
-	void feedFile(const std::string &path);
+	void feedFile(const std::string &path, uint64_t offset = 0);
+	/* One read (insertCount(seq.s, seq.l), src/FingerPrint.hpp:89-103): append to the staging batch. */
+	void feedRead(const char *seq, uint64_t len);
 	void flush();
+	/* Sink interface of the block-parallel ingest (parallel_fastq.hpp) */
+	bool has_room(uint64_t len) const { return !(m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)); }
+	void feed(const char *seq, uint64_t len) { feedRead(seq, len); }
+	void discard() { m_fill = 0; m_nReads = 0; }
+	void begin_block(size_t) { }
+	/* flush + close the lane (its totals fold into the context); the Feeder must not be fed afterwards */
+	void finish();
 	bool earlyTerm() const { return m_earlyTerm; }
-	ntsm_ctx *ctx() const { return m_ctx; }
 
 private:
 	[[noreturn]] void die(int rc, const char *what) const;
 	const Options &m_opt;
+	void openLane();
 	ntsm_ctx *m_ctx = nullptr;
+	ntsm_lane *m_lane = nullptr;
+	bool m_useLane = false;
 	uint64_t m_maxCounts = 0;
 	uint8_t *m_bases = nullptr;
 	uint64_t *m_readEnd = nullptr;
@@ -71,7 +88,13 @@ private:
 	Options m_opt;
 	SiteSet m_sites;
 	uint64_t m_maxCounts = 0;
-	std::vector<std::unique_ptr<Feeder>> m_feeders;      /* [0] always exists; more with -t N and several files */
+	Feeder &feederFor(size_t t);                         /* thread t's lane on device devices[t % n] (created on first use) */
+	void closeLanes();
+	std::thread m_poolThread;                            /* pins the staging pool while the sites are parsed */
+	std::vector<ntsm_ctx *> m_ctx;                       /* one GPU context per distinct -g device, [0] = first device */
+	std::vector<int> m_ctxDevice;
+	std::unique_ptr<Feeder> m_main;                      /* context [0]'s own staging: single-threaded and -m runs */
+	std::vector<std::unique_ptr<Feeder>> m_lanes;        /* -t N: one producer lane per host thread */
 	/* results */
 	bool m_fetched = false;
 	ntsm_totals m_totals {};

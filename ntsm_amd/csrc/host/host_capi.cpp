@@ -5,6 +5,8 @@
 #include <iostream>
 #include <sstream>
 
+#include <algorithm>
+#include "parallel_fastq.hpp"
 #include "report.hpp"
 #include "seq_reader.hpp"
 #include "site_set.hpp"
@@ -71,6 +73,76 @@ int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint
 }
 
 void ntsm_host_free(void *p) { free(p); }
+
+namespace {
+/* Test sink of the block-parallel ingest: a small "staging" buffer whose flushes are kept as (block, order) chunks */
+struct CollectSink {
+	struct Chunk { size_t block; std::vector<uint8_t> bases; std::vector<uint64_t> lens; };
+	uint64_t cap = 0;
+	size_t cur = 0;
+	std::vector<uint8_t> bases;
+	std::vector<uint64_t> lens;
+	std::vector<Chunk> out;
+	bool has_room(uint64_t len) const { return lens.empty() || bases.size() + len + 1 <= cap; }
+	void feed(const char *seq, uint64_t len) { bases.insert(bases.end(), seq, seq + len); bases.push_back('N'); lens.push_back(len); }
+	void flush() { if (!lens.empty()) { out.push_back(Chunk { cur, std::move(bases), std::move(lens) }); bases.clear(); lens.clear(); } }
+	void discard() { bases.clear(); lens.clear(); }
+	void begin_block(size_t b) { cur = b; }
+};
+} // namespace
+
+int ntsm_host_flatten_parallel(const char *path, unsigned n_threads, uint64_t block_bytes, uint8_t **bases,
+		uint64_t *n_bytes, uint64_t **read_end, uint64_t *n_reads, uint64_t *n_blocks, uint64_t *n_parallel,
+		uint64_t *resume)
+{
+	FILE *probe = fopen(path, "rb");
+	if (!probe) return -1;
+	fclose(probe);
+	ntsm::ParallelFastq pf;
+	if (!pf.open(path, block_bytes)) return 1;
+	if (n_threads == 0) n_threads = 1;
+	std::vector<CollectSink> sinks(n_threads);
+	std::vector<CollectSink *> ptrs;
+	for (auto &s : sinks) { s.cap = block_bytes / 5 + 64; ptrs.push_back(&s); }     /* several flushes per block */
+	const ntsm::ParallelFastq::Result r = pf.run(ptrs);
+	std::vector<const CollectSink::Chunk *> order;
+	for (auto &s : sinks) {
+		if (!s.lens.empty()) return -2;                                             /* staged but never committed nor dropped */
+		for (auto &c : s.out) order.push_back(&c);
+	}
+	/* chunks of one block come from one thread in feed order; stable sort by block restores file order */
+	std::stable_sort(order.begin(), order.end(), [](const CollectSink::Chunk *a, const CollectSink::Chunk *b) { return a->block < b->block; });
+	std::vector<uint8_t> b;
+	std::vector<uint64_t> e;
+	for (const CollectSink::Chunk *c : order) {
+		uint64_t off = 0;
+		for (uint64_t len : c->lens) {
+			b.insert(b.end(), c->bases.begin() + (long) off, c->bases.begin() + (long) (off + len + 1));
+			e.push_back(b.size() - 1);
+			off += len + 1;
+		}
+	}
+	if (n_parallel) *n_parallel = e.size();
+	if (resume) *resume = r.resume;
+	if (e.size() != r.records) return -2;
+	if (!r.complete) {                                                              /* sequential reader takes over */
+		ntsm::SeqReader rd;
+		if (!rd.open(path, r.resume)) return -1;
+		for (int64_t l = rd.next(); l >= 0; l = rd.next()) {
+			b.insert(b.end(), rd.seq_data(), rd.seq_data() + l);
+			e.push_back(b.size());
+			b.push_back('N');
+		}
+	}
+	*bases = (uint8_t *) malloc(b.size() + 16);
+	memcpy(*bases, b.data(), b.size());
+	*n_bytes = b.size();
+	*read_end = (uint64_t *) malloc((e.size() + 1) * sizeof(uint64_t));
+	memcpy(*read_end, e.data(), e.size() * sizeof(uint64_t));
+	*n_reads = e.size();
+	if (n_blocks) *n_blocks = pf.n_blocks();
+	return 0;
+}
 
 int ntsm_host_format_counts(const ntsm_sites *s, const uint64_t *counts, uint64_t total_kmers, char **out, size_t *len)
 {

@@ -139,11 +139,19 @@ int main(int argc, char *argv[])
 		exit(EXIT_FAILURE);
 	}
 	if (const char *bb = getenv("NTSM_BATCH_BYTES")) opt.batch_bytes = strtoull(bb, nullptr, 10);   /* staging slot size */
+	if (const char *pb = getenv("NTSM_BLOCK_BYTES")) opt.block_bytes = strtoull(pb, nullptr, 10);   /* block-parallel ingest block size */
 	const auto t0 = std::chrono::steady_clock::now();
+	const bool phases = opt.phase_times = getenv("NTSM_PHASE_TIMES") != nullptr;     /* diagnostics: where the wall time goes */
+	auto lap = [&](const char *what) {
+		if (phases) std::cerr << "[phase] " << what << ": " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
+	};
 	ntsm::FingerPrint fp(opt);
+	lap("sites loaded + first GPU context");
 	fp.computeCounts(inputFiles);
+	lap("reads counted");
 	fp.printOptionalHeader(std::cout);
 	fp.printCountsMax(std::cout);
+	lap("counts printed");
 	std::cerr << fp.printInfoSummary() << std::endl;
 	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	std::cerr << "Time: " << secs << " s Memory: " << rss_kb() << " kbytes" << std::endl;

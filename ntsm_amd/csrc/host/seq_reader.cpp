@@ -5,12 +5,13 @@
 
 namespace ntsm {
 
-bool SeqReader::open(const std::string &path)
+bool SeqReader::open(const std::string &path, uint64_t offset)
 {
 	close();
 	f_ = gzopen(path.c_str(), "r");
 	if (!f_) return false;
 	gzbuffer(f_, 1 << 20);
+	if (offset && gzseek(f_, (z_off_t) offset, SEEK_SET) < 0) { close(); return false; }
 	buf_.resize(kBuf);
 	beg_ = end_ = 0;
 	eof_ = false;

@@ -30,7 +30,8 @@ public:
 	SeqReader(const SeqReader &) = delete;
 	SeqReader &operator=(const SeqReader &) = delete;
 
-	bool open(const std::string &path);
+	/* offset: start reading at this byte of the (uncompressed) stream; it must be a record boundary */
+	bool open(const std::string &path, uint64_t offset = 0);
 	void close();
 	/* Next record: returns the sequence length (>= 0), -1 at end of file, -2 on a truncated
 	 * quality block, -3 on a stream error.  seq()/name() are valid until the next call. */

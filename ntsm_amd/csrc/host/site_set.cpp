@@ -7,6 +7,39 @@
 
 namespace ntsm {
 
+namespace {
+
+/* Stable LSD radix sort of (key, idx) pairs by key, 11 bits per pass; passes whose digit is constant are skipped. */
+void radix_sort_pairs(std::vector<uint64_t> &key, std::vector<uint32_t> &idx)
+{
+	const size_t n = key.size();
+	if (n < 2) return;
+	uint64_t all_or = 0, all_and = ~0ull;
+	for (uint64_t x : key) { all_or |= x; all_and &= x; }
+	const uint64_t varying = all_or ^ all_and;                  /* bits that differ somewhere */
+	std::vector<uint64_t> key2(n);
+	std::vector<uint32_t> idx2(n);
+	constexpr int B = 11;
+	std::vector<size_t> count((size_t) 1 << B);
+	for (int sh = 0; sh < 64; sh += B) {
+		if (((varying >> sh) & ((1u << B) - 1)) == 0) continue;
+		std::fill(count.begin(), count.end(), 0);
+		for (size_t i = 0; i < n; ++i) count[(key[i] >> sh) & ((1u << B) - 1)]++;
+		size_t run = 0;
+		for (size_t d = 0; d < count.size(); ++d) { const size_t c = count[d]; count[d] = run; run += c; }
+		for (size_t i = 0; i < n; ++i) {
+			const size_t d = (key[i] >> sh) & ((1u << B) - 1);
+			const size_t o = count[d]++;
+			key2[o] = key[i];
+			idx2[o] = idx[i];
+		}
+		key.swap(key2);
+		idx.swap(idx2);
+	}
+}
+
+} // namespace
+
 bool SiteSet::load(const std::string &path, unsigned kk, bool allow_dupes, std::ostream &err)
 {
 	k = kk;
@@ -14,66 +47,63 @@ bool SiteSet::load(const std::string &path, unsigned kk, bool allow_dupes, std::
 	n_erased = 0;
 	SeqReader rd;
 	if (!rd.open(path)) return false;
-	/* flat open-addressing index: canonical code -> provisional key index (first-seen order); grows by doubling */
-	std::vector<uint64_t> tab_key(1u << 16, ~0ull);
-	std::vector<int64_t> tab_idx(1u << 16, 0);
-	uint64_t tab_mask = tab_key.size() - 1;
-	auto mix = [](uint64_t x) { x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; return x; };
-	auto lookup = [&](uint64_t code) -> int64_t {            /* slot of code, or of the empty slot where it belongs */
-		uint64_t i = mix(code) & tab_mask;
-		while (tab_key[i] != ~0ull && tab_key[i] != code) i = (i + 1) & tab_mask;
-		return (int64_t) i;
-	};
-	std::vector<uint64_t> prov;                            /* provisional keys in first-seen order */
-	std::vector<uint8_t> is_dup;                           /* parallel to prov: seen more than once */
-	uint64_t entry = 0;
-	for (int64_t l = rd.next(); l >= 0; l = rd.next(), ++entry) {
-		const bool is_ref = (entry % 2 == 0);
+	/* Pass 1: every k-mer occurrence of the file in stream order (the reference inserts them one by one into
+	 * m_counts, src/FingerPrint.hpp:507-556).  "Seen before" is decided afterwards by sorting the occurrences by
+	 * code -- 3-5x faster than 1.5 M dependent probes of a 50 MB hash table, with identical results: within equal
+	 * codes the stable sort keeps stream order, so the first element of a group is the first-seen occurrence. */
+	std::vector<uint64_t> occ_code;
+	std::vector<uint32_t> occ_pos;
+	std::vector<uint64_t> rec_begin;                           /* first occurrence of every record; [n_rec] = total */
+	std::vector<std::string> rec_name;
+	for (int64_t l = rd.next(); l >= 0; l = rd.next()) {
+		rec_begin.push_back(occ_code.size());
+		rec_name.push_back(rd.name());
+		for_each_kmer(rd.seq_data(), (uint64_t) l, k, [&](uint64_t code, uint64_t pos) {
+			occ_code.push_back(code);
+			occ_pos.push_back((uint32_t) pos);
+		});
+	}
+	const size_t n_occ = occ_code.size(), n_rec = rec_name.size();
+	rec_begin.push_back(n_occ);
+	if (n_occ > 0xFFFFFFF0ull) { err << "too many k-mers in " << path << std::endl; return false; }
+	/* Pass 2: sort (code, occurrence) and classify */
+	std::vector<uint8_t> later(n_occ, 0);                      /* occurrence of a code that was seen before */
+	std::vector<uint8_t> dup_first(n_occ, 0);                  /* first occurrence of a code that occurs again */
+	{
+		std::vector<uint64_t> sk(occ_code);
+		std::vector<uint32_t> si(n_occ);
+		for (size_t i = 0; i < n_occ; ++i) si[i] = (uint32_t) i;
+		radix_sort_pairs(sk, si);
+		for (size_t i = 0; i < n_occ;) {
+			size_t j = i + 1;
+			while (j < n_occ && sk[j] == sk[i]) later[si[j++]] = 1;
+			if (j - i > 1) dup_first[si[i]] = 1;
+			i = j;
+		}
+	}
+	/* Pass 3: stream order again -- warnings, allele lists, keys (first-seen order minus erased duplicates) */
+	ref.reserve(n_rec / 2 + 1);
+	var.reserve(n_rec / 2 + 1);
+	ids.reserve(n_rec / 2 + 1);
+	for (size_t r = 0; r < n_rec; ++r) {
+		const bool is_ref = (r % 2 == 0);
 		std::vector<std::vector<int64_t>> &side = is_ref ? ref : var;
 		side.emplace_back();
 		std::vector<int64_t> &list = side.back();
-		for_each_kmer(rd.seq_data(), (uint64_t) l, k, [&](uint64_t code, uint64_t pos) {
-			int64_t slot = lookup(code);
-			if (tab_key[(size_t) slot] == code) {
-				err << "Warning: " << rd.name() << " of " << (is_ref ? "REF" : "VAR")
-				    << " file has a k-mer collision at pos: " << pos << std::endl;
-				is_dup[(size_t) tab_idx[(size_t) slot]] = 1;
+		for (uint64_t o = rec_begin[r]; o < rec_begin[r + 1]; ++o) {
+			if (later[o]) {
+				err << "Warning: " << rec_name[r] << " of " << (is_ref ? "REF" : "VAR")
+				    << " file has a k-mer collision at pos: " << occ_pos[o] << std::endl;
+			} else if (dup_first[o] && !allow_dupes) {
+				++n_erased;                                          /* :557-563: erased again, stays in this allele's list */
+				list.push_back(kErased);
 			} else {
-				if (2 * (prov.size() + 1) > tab_key.size()) {          /* keep the load below 0.5 */
-					std::vector<uint64_t> nk(tab_key.size() * 2, ~0ull);
-					std::vector<int64_t> ni(tab_key.size() * 2, 0);
-					const uint64_t nm = nk.size() - 1;
-					for (size_t j = 0; j < tab_key.size(); ++j)
-						if (tab_key[j] != ~0ull) {
-							uint64_t i = mix(tab_key[j]) & nm;
-							while (nk[i] != ~0ull) i = (i + 1) & nm;
-							nk[i] = tab_key[j];
-							ni[i] = tab_idx[j];
-						}
-					tab_key.swap(nk);
-					tab_idx.swap(ni);
-					tab_mask = nm;
-					slot = lookup(code);
-				}
-				tab_key[(size_t) slot] = code;
-				tab_idx[(size_t) slot] = (int64_t) prov.size();
-				list.push_back((int64_t) prov.size());
-				prov.push_back(code);
-				is_dup.push_back(0);
+				list.push_back((int64_t) keys.size());
+				keys.push_back(occ_code[o]);
 			}
-		});
-		if (is_ref) ids.push_back(rd.name());
+		}
+		if (is_ref) ids.push_back(std::move(rec_name[r]));
 	}
-	/* final key set = first-seen order minus erased duplicates; remap the allele lists */
-	std::vector<int64_t> remap(prov.size(), kErased);
-	for (size_t i = 0; i < prov.size(); ++i) {
-		if (!allow_dupes && is_dup[i]) { ++n_erased; continue; }
-		remap[i] = (int64_t) keys.size();
-		keys.push_back(prov[i]);
-	}
-	for (auto *side : { &ref, &var })
-		for (auto &list : *side)
-			for (auto &ix : list) ix = remap[(size_t) ix];
 	return true;
 }
 

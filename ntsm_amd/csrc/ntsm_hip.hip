@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ntsm_hip.h"
@@ -545,9 +546,54 @@ namespace {
 constexpr int kTileC = 128;                 /* stream bytes per thread and tile */
 constexpr int kTimingPool = 256;
 
+/* Process-wide pool of pinned host memory (ntsm_staging_pool): pinning costs ~0.4 ms/MiB and the driver serialises
+ * it, so staging slots are carved out of one early allocation instead of being pinned one by one. */
+struct PinnedPool {
+	std::mutex mu;
+	uint8_t *base = nullptr;
+	uint64_t size = 0, bump = 0, outstanding = 0;
+	std::vector<std::pair<uint64_t, uint64_t>> free_list;      /* (offset, bytes) of returned pieces, reused by exact size */
+};
+PinnedPool g_pool;
+
+void *pool_alloc(uint64_t bytes)
+{
+	bytes = (bytes + 4095) & ~4095ull;
+	std::lock_guard<std::mutex> lk(g_pool.mu);
+	if (!g_pool.base) return nullptr;
+	for (size_t i = 0; i < g_pool.free_list.size(); ++i)
+		if (g_pool.free_list[i].second == bytes) {
+			void *p = g_pool.base + g_pool.free_list[i].first;
+			g_pool.free_list.erase(g_pool.free_list.begin() + (long) i);
+			g_pool.outstanding++;
+			return p;
+		}
+	if (g_pool.bump + bytes > g_pool.size) return nullptr;
+	void *p = g_pool.base + g_pool.bump;
+	g_pool.bump += bytes;
+	g_pool.outstanding++;
+	return p;
+}
+
+bool pool_free(void *ptr, uint64_t bytes)
+{
+	bytes = (bytes + 4095) & ~4095ull;
+	std::lock_guard<std::mutex> lk(g_pool.mu);
+	uint8_t *p = (uint8_t *) ptr;
+	if (!g_pool.base || p < g_pool.base || p >= g_pool.base + g_pool.size) return false;
+	g_pool.free_list.emplace_back((uint64_t) (p - g_pool.base), bytes);
+	if (--g_pool.outstanding == 0) {                            /* everything came back: start over with one free region */
+		g_pool.free_list.clear();
+		g_pool.bump = 0;
+	}
+	return true;
+}
+
 struct Slot {
 	uint8_t *h_bases = nullptr, *d_bases = nullptr;
 	uint64_t *h_read_end = nullptr, *d_read_end = nullptr;
+	uint64_t h_bases_bytes = 0, h_ends_bytes = 0;
+	bool ends_on_device = true;                /* false (lanes): read_end never leaves the host, plain malloc */
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;                 /* last use of the host buffer finished */
 	bool busy = false, acquired = false;
@@ -620,6 +666,20 @@ struct ntsm_ctx {
 	int ev_next = 0;
 	uint64_t t_launches = 0;
 	double t_ms = 0;
+	/* producer lanes (ntsm_lane_*): several host threads feeding this context */
+	std::mutex mu;                             /* guards open_lanes, the lane totals fold-in and the timing pool */
+	int open_lanes = 0;
+};
+
+/* One producer thread's private staging: two pinned slots + their device mirrors and streams.  All lanes of a
+ * context count into the same tables (atomic adds), which is the reference's omp-over-files with a shared m_counts
+ * and `#pragma omp atomic` (src/FingerPrint.hpp:47, :94-99). */
+struct ntsm_lane {
+	ntsm_ctx *c = nullptr;
+	Slot slot[2];
+	int next_slot = 0;
+	uint64_t cap_bytes = 0, cap_reads = 0;
+	uint64_t total_bases = 0, reads_consumed = 0;     /* folded into the context by ntsm_lane_close */
 };
 
 namespace {
@@ -779,12 +839,22 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	return NTSM_OK;
 }
 
-int alloc_slot(ntsm_ctx *c, Slot &s)
+int alloc_slot(Slot &s, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device)
 {
-	HIPCHK(hipHostMalloc(&s.h_bases, c->cap_bytes + 64, hipHostMallocDefault));
-	HIPCHK(hipHostMalloc(&s.h_read_end, c->cap_reads * sizeof(uint64_t), hipHostMallocDefault));
-	HIPCHK(hipMalloc(&s.d_bases, c->cap_bytes + 64));
-	HIPCHK(hipMalloc(&s.d_read_end, c->cap_reads * sizeof(uint64_t)));
+	s.ends_on_device = ends_on_device;
+	s.h_bases_bytes = cap_bytes + 64;
+	s.h_ends_bytes = cap_reads * sizeof(uint64_t);
+	s.h_bases = (uint8_t *) pool_alloc(s.h_bases_bytes);
+	if (!s.h_bases) HIPCHK(hipHostMalloc(&s.h_bases, s.h_bases_bytes, hipHostMallocPortable));
+	if (ends_on_device) {
+		s.h_read_end = (uint64_t *) pool_alloc(s.h_ends_bytes);
+		if (!s.h_read_end) HIPCHK(hipHostMalloc(&s.h_read_end, s.h_ends_bytes, hipHostMallocPortable));
+		HIPCHK(hipMalloc(&s.d_read_end, s.h_ends_bytes));
+	} else {
+		s.h_read_end = (uint64_t *) malloc(s.h_ends_bytes);
+		if (!s.h_read_end) return NTSM_ERR_NOMEM;
+	}
+	HIPCHK(hipMalloc(&s.d_bases, cap_bytes + 64));
 	if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
 	if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
 	s.busy = false;
@@ -794,8 +864,11 @@ int alloc_slot(ntsm_ctx *c, Slot &s)
 
 void free_slot(Slot &s)
 {
-	if (s.h_bases) (void) hipHostFree(s.h_bases);
-	if (s.h_read_end) (void) hipHostFree(s.h_read_end);
+	if (s.h_bases && !pool_free(s.h_bases, s.h_bases_bytes)) (void) hipHostFree(s.h_bases);
+	if (s.h_read_end) {
+		if (!s.ends_on_device) free(s.h_read_end);
+		else if (!pool_free(s.h_read_end, s.h_ends_bytes)) (void) hipHostFree(s.h_read_end);
+	}
 	if (s.d_bases) (void) hipFree(s.d_bases);
 	if (s.d_read_end) (void) hipFree(s.d_read_end);
 	s.h_bases = s.d_bases = nullptr;
@@ -844,7 +917,9 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	uint64_t grid = c->grid_blocks > 0 ? (uint64_t) c->grid_blocks : std::min<uint64_t>(65536, std::max<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles / 8));
 	if (grid > p.n_tiles) grid = p.n_tiles;
 	int ev = -1;
+	std::unique_lock<std::mutex> timing_lock(c->mu, std::defer_lock);   /* the event pool is shared by all lanes */
 	if (c->timing) {
+		timing_lock.lock();
 		ev = c->ev_next;
 		c->ev_next = (c->ev_next + 1) % kTimingPool;
 		if (c->ev_used[ev]) {                             /* recycle: fold the old measurement in */
@@ -1130,7 +1205,7 @@ int ntsm_staging_acquire(ntsm_ctx *c, uint8_t **bases, uint64_t *cap_bytes, uint
 	HIPCHK(hipSetDevice(c->device));
 	Slot &s = c->slot[c->next_slot];
 	if (!s.h_bases) {
-		int rc = alloc_slot(c, s);
+		int rc = alloc_slot(s, c->cap_bytes, c->cap_reads, true);
 		if (rc) return rc;
 	}
 	int rc = wait_slot(s);
@@ -1157,6 +1232,135 @@ int ntsm_submit_staged(ntsm_ctx *c, uint64_t n_bytes, uint32_t n_reads)
 	HIPCHK(hipSetDevice(c->device));
 	rc = submit_slot(c, s, n_bytes, n_reads);
 	c->next_slot ^= 1;
+	return rc;
+}
+
+int ntsm_warmup(int device)
+{
+	int n_dev = 0;
+	hipError_t e = hipGetDeviceCount(&n_dev);
+	if (e != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+		g_last_hip = (int) e;
+		return NTSM_ERR_NO_DEVICE;
+	}
+	HIPCHK(hipSetDevice(device));
+	HIPCHK(hipFree(nullptr));                             /* forces runtime + device context initialisation */
+	return NTSM_OK;
+}
+
+int ntsm_staging_pool(uint64_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_pool.mu);
+	if (bytes == 0) {                                     /* release */
+		if (g_pool.outstanding) return NTSM_ERR_STATE;
+		if (g_pool.base) HIPCHK(hipHostFree(g_pool.base));
+		g_pool.base = nullptr;
+		g_pool.size = g_pool.bump = 0;
+		g_pool.free_list.clear();
+		return NTSM_OK;
+	}
+	if (g_pool.base) return g_pool.size >= bytes ? NTSM_OK : NTSM_ERR_STATE;
+	bytes = (bytes + 4095) & ~4095ull;
+	void *p = nullptr;
+	HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocPortable));
+	g_pool.base = (uint8_t *) p;
+	g_pool.size = bytes;
+	g_pool.bump = 0;
+	return NTSM_OK;
+}
+
+int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lane **out)
+{
+	if (!c || !out) return NTSM_ERR_ARG;
+	*out = nullptr;
+	if (c->max_hits) return NTSM_ERR_STATE;               /* -m is defined on ONE ordered stream of reads */
+	if (cap_bytes == 0) cap_bytes = c->cap_bytes;
+	if (cap_reads == 0) cap_reads = cap_bytes / 64 + 16;
+	if (cap_bytes < 4096 || cap_reads < 16) return NTSM_ERR_ARG;
+	HIPCHK(hipSetDevice(c->device));
+	ntsm_lane *l = new (std::nothrow) ntsm_lane();
+	if (!l) return NTSM_ERR_NOMEM;
+	l->c = c;
+	l->cap_bytes = cap_bytes;
+	l->cap_reads = cap_reads;
+	for (auto &s : l->slot) {
+		int rc = alloc_slot(s, cap_bytes, cap_reads, false);
+		if (rc) {
+			for (auto &q : l->slot) {
+				free_slot(q);
+				if (q.stream) (void) hipStreamDestroy(q.stream);
+				if (q.done) (void) hipEventDestroy(q.done);
+			}
+			delete l;
+			return rc;
+		}
+	}
+	{
+		std::lock_guard<std::mutex> lk(c->mu);
+		c->open_lanes++;
+		c->reduced = false;
+	}
+	*out = l;
+	return NTSM_OK;
+}
+
+int ntsm_lane_acquire(ntsm_lane *l, uint8_t **bases, uint64_t *cap_bytes, uint64_t **read_end, uint64_t *cap_reads)
+{
+	if (!l || !bases || !cap_bytes || !read_end || !cap_reads) return NTSM_ERR_ARG;
+	HIPCHK(hipSetDevice(l->c->device));
+	Slot &s = l->slot[l->next_slot];
+	int rc = wait_slot(s);
+	if (rc) return rc;
+	s.acquired = true;
+	*bases = s.h_bases;
+	*cap_bytes = l->cap_bytes;
+	*read_end = s.h_read_end;
+	*cap_reads = l->cap_reads;
+	return NTSM_OK;
+}
+
+int ntsm_lane_submit(ntsm_lane *l, uint64_t n_bytes, uint32_t n_reads)
+{
+	if (!l) return NTSM_ERR_ARG;
+	Slot &s = l->slot[l->next_slot];
+	if (!s.acquired) return NTSM_ERR_STATE;
+	s.acquired = false;
+	if (n_bytes > l->cap_bytes || n_reads > l->cap_reads) return NTSM_ERR_ARG;
+	int rc = check_layout(s.h_read_end, n_reads, n_bytes);
+	if (rc) return rc;
+	if (n_reads == 0) return NTSM_OK;
+	ntsm_ctx *c = l->c;
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, n_bytes, hipMemcpyHostToDevice, s.stream));
+	rc = launch_count(c, s.stream, s.d_bases, 0, n_bytes, nullptr, 0, false, +1);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(s.done, s.stream));
+	s.busy = true;
+	l->total_bases += n_bytes - n_reads;
+	l->reads_consumed += n_reads;
+	l->next_slot ^= 1;
+	return NTSM_OK;
+}
+
+int ntsm_lane_close(ntsm_lane *l)
+{
+	if (!l) return NTSM_ERR_ARG;
+	ntsm_ctx *c = l->c;
+	int rc = NTSM_OK;
+	if (hipSetDevice(c->device) != hipSuccess) rc = NTSM_ERR_HIP;
+	for (auto &s : l->slot) {
+		if (s.stream && hipStreamSynchronize(s.stream) != hipSuccess) rc = NTSM_ERR_HIP;
+		free_slot(s);
+		if (s.stream) (void) hipStreamDestroy(s.stream);
+		if (s.done) (void) hipEventDestroy(s.done);
+	}
+	{
+		std::lock_guard<std::mutex> lk(c->mu);
+		c->total_bases += l->total_bases;
+		c->reads_consumed += l->reads_consumed;
+		c->open_lanes--;
+	}
+	delete l;
 	return rc;
 }
 
@@ -1201,6 +1405,10 @@ int ntsm_count_resident(ntsm_ctx *c, const void *d_bases, uint64_t n_bytes, cons
 int ntsm_sync(ntsm_ctx *c, ntsm_totals *t)
 {
 	if (!c) return NTSM_ERR_ARG;
+	{
+		std::lock_guard<std::mutex> lk(c->mu);
+		if (c->open_lanes) return NTSM_ERR_STATE;             /* lanes hold batches this call cannot see: close them first */
+	}
 	HIPCHK(hipSetDevice(c->device));
 	for (auto &s : c->slot) {
 		if (s.stream) HIPCHK(hipStreamSynchronize(s.stream));

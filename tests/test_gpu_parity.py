@@ -430,6 +430,78 @@ def test_cli_threads_over_files(nt, tmp_path):
     assert p.returncode == 0 and p.stdout == open(os.path.join(G, "expected", c["stdout"]), "rb").read()
 
 
+def test_producer_lanes_share_one_context(nt, tmp_path):
+    """ntsm_lane_*: four host threads, each with its own lane, feed ONE context concurrently (the reference's
+    omp-over-files with a shared m_counts and atomic increments, src/FingerPrint.hpp:47,:94-99).  Counts and totals
+    equal the oracle's on the concatenated reads; state rules of the lane API."""
+    import threading
+    s = nt.SynthShort(sites_seed=5, n_sites=3000, read_seed=21, p_embed=0.2, sites_path=str(tmp_path / "s.fa"))
+    sites = nt.Sites(str(tmp_path / "s.fa"))
+    n, per = 240_000, 5_000
+    flat = s.host_bytes(0, n)
+    fp = OracleFP(str(tmp_path / "s.fa"))
+    fp.process_flat(flat, s.read_end(n))
+    ctx = nt.Context(sites.keys)
+    nt.warmup(0)
+    lanes = [ctx.open_lane(1 << 20) for _ in range(4)]
+    with pytest.raises(nt.NtsmError):
+        ctx.sync()                                           # lanes open: NTSM_ERR_STATE
+    errs = []
+
+    def work(t):
+        try:
+            ends = s.read_end(per)
+            for b in range(t, n // per, 4):
+                lanes[t].submit(flat[b * per * s.stride:(b + 1) * per * s.stride], ends)
+        except Exception as e:                               # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs
+    with pytest.raises(nt.NtsmError):
+        lanes[0].submit(flat[:2_000_000], s.read_end(2_000_000 // s.stride))     # larger than the 1 MiB slot
+    for ln in lanes:
+        ln.close()
+    t = ctx.sync()
+    assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (fp.total_kmers, fp.total_hits, fp.total_bases, n)
+    assert np.array_equal(ctx.counts(), fp.kmers()[2])
+    # the context's own staging still works after the lanes, and adds on top
+    ctx.submit(flat[:per * s.stride], s.read_end(per))
+    assert ctx.sync().reads_consumed == n + per
+    ctx.close()
+    armed = nt.Context(sites.keys, max_hits=10)
+    with pytest.raises(nt.NtsmError):
+        armed.open_lane()                                    # -m is defined on one ordered stream
+    armed.close()
+
+
+def test_cli_block_parallel_single_file(nt, tmp_path):
+    """-t N on ONE plain FASTQ: the file is cut into blocks parsed by all N threads (parallel_fastq.hpp); counts and
+    summary must be the single-thread bytes, also mixed with files that take the per-file path."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    inp = os.path.join(G, "inputs")
+    sites_fa = str(tmp_path / "s.fa")
+    s = nt.SynthShort(sites_seed=20241218, n_sites=1000, read_seed=77, p_embed=0.05, sites_path=sites_fa)
+    fq = str(tmp_path / "big.fq")
+    s.write_fastq(fq, 0, 60000)
+    extra = [os.path.join(inp, "reads600.fq.gz"), os.path.join(inp, "long.fa")]
+    lines = open(fq, "rb").read().split(b"\n")
+    lines[100001] = lines[100001][:60] + b"\n" + lines[100001][60:]   # a wrapped record: parallel prefix, sequential rest
+    wrapped = str(tmp_path / "wrapped.fq")
+    open(wrapped, "wb").write(b"\n".join(lines))
+    for files in ([fq], [fq] + extra, [wrapped, fq]):
+        base = subprocess.run([exe, "-s", sites_fa] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert base.returncode == 0, base.stderr[-400:]
+        for t, blk in (("4", "1048576"), ("8", "300000"), ("3", "65536")):
+            env = dict(os.environ, NTSM_BLOCK_BYTES=blk)
+            p = subprocess.run([exe, "-s", sites_fa, "-t", t, "-v"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert p.returncode == 0, p.stderr[-400:]
+            assert p.stdout == base.stdout
+            assert _summary(p.stderr) == _summary(base.stderr)
+            assert b"block-parallel" in p.stderr
+
+
 def test_fuzz_arbitrary_bytes(nt, tmp_path):
     """Arbitrary byte soup (all 256 values, long valid runs, runs of raw 0..3 codes, lowercase, U): both kernels
     against the oracle, with site k-mers cut out of the stream itself so that hits are frequent."""

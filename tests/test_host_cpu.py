@@ -185,3 +185,105 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
         p = subprocess.run([exe, os.path.join(G, "inputs", sites), str(k), str(dupes)] + reads, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert p.returncode == 0, (sites, k, p.stderr.decode()[-2000:])
         assert b"records=" in p.stdout
+
+
+def test_block_parallel_fastq_ingest(nt, tmp_path):
+    """Block-parallel single-pass FASTQ ingest (ordered commit) == the sequential kseq-equivalent reader on every
+    input it accepts: strict files are consumed entirely in parallel; at the first record that is not plain 4-line
+    FASTQ the parallel phase stops at a record boundary and the sequential reader continues from that byte."""
+    import gzip
+    from ntsm_amd.capi import flatten_file_parallel
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=33, p_embed=0.2)
+    fq = str(tmp_path / "p.fq")
+    s.write_fastq(fq, 0, 30000)                                     # ~9.3 MB
+    size = os.path.getsize(fq)
+    seq_b, seq_e, _ = nt.flatten_file(fq)
+    for threads, block in ((4, 1 << 20), (3, 700_001), (8, 64 << 10), (1, 1 << 20), (16, 4096)):
+        r = flatten_file_parallel(fq, threads, block)
+        assert r is not None
+        assert np.array_equal(r[0], seq_b) and np.array_equal(r[1], seq_e)
+        assert r[2]["parallel_records"] == 30000 and r[2]["resume"] == size and r[2]["blocks"] == -(-size // block)
+    # adversarial but strict: qualities made of '@' and '+', names containing '+', ragged read lengths (records
+    # longer and shorter than a block)
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(40000):
+        n = int(rng.integers(1, 200)) if i % 5000 else 30000
+        sq = "".join(rng.choice(list("ACGTN"), size=n))
+        q = "".join(rng.choice(list("@+>I"), size=n))
+        recs.append("@r%d+x @y\n%s\n+r%d\n%s\n" % (i, sq, i, q))
+    adv = str(tmp_path / "adv.fq")
+    open(adv, "w").write("".join(recs))
+    a_b, a_e, rc = nt.flatten_file(adv)
+    assert rc == -1 and len(a_e) == 40000
+    for threads, block in ((4, 256 << 10), (7, 99_991), (5, 8192)):
+        r = flatten_file_parallel(adv, threads, block)
+        assert r is not None and np.array_equal(r[0], a_b) and np.array_equal(r[1], a_e)
+        assert r[2]["parallel_records"] == 40000
+    # files that stop being strict somewhere: parallel prefix + sequential rest == sequential reader
+    raw = open(fq, "rb").read()
+    lines = raw.split(b"\n")
+    cases = {"crlf.fq": raw.replace(b"\n", b"\r\n"), "noeol.fq": raw[:-1]}
+    w = list(lines)
+    w[40001] = w[40001][:70] + b"\n" + w[40001][70:]                # one wrapped sequence line in the middle of the file
+    cases["wrapped.fq"] = b"\n".join(w)
+    t = list(lines)
+    del t[60003]                                                    # a record without its quality line: kseq ends the file there
+    cases["truncq.fq"] = b"\n".join(t)
+    f = list(lines)
+    f[80000] = b">" + f[80000][1:]                                  # a FASTA record in the middle
+    del f[80002:80004]
+    cases["mixed.fq"] = b"\n".join(f)
+    e = list(lines)
+    e[20001] = b""                                                  # empty sequence line
+    cases["emptyseq.fq"] = b"\n".join(e)
+    for name, data in cases.items():
+        pth = str(tmp_path / name)
+        open(pth, "wb").write(data)
+        ref_b, ref_e, ref_rc = nt.flatten_file(pth)
+        for threads, block in ((4, 1 << 20), (6, 50_000)):
+            r = flatten_file_parallel(pth, threads, block)
+            assert r is not None, name
+            assert np.array_equal(r[0], ref_b) and np.array_equal(r[1], ref_e), (name, threads, block)
+            assert r[2]["resume"] < len(data) or name == "noeol.fq" and r[2]["resume"] <= len(data), name
+        if name == "crlf.fq":
+            assert r[2]["parallel_records"] == 0 and r[2]["resume"] == 0
+        if name == "wrapped.fq":
+            assert r[2]["parallel_records"] == 10000
+    # not eligible at all: gzip, FASTA, junk before the first header, small files
+    bad = {"junk.fq": b"junk\n" + raw, "tiny.fq": raw[:50_000].rsplit(b"\n@", 1)[0] + b"\n",
+           "fasta.fa": b"\n".join(b">" + lines[i][1:] + b"\n" + lines[i + 1] for i in range(0, len(lines) - 1, 4)) + b"\n"}
+    for name, data in bad.items():
+        pth = str(tmp_path / name)
+        open(pth, "wb").write(data)
+        assert flatten_file_parallel(pth, 4, 1 << 20) is None, name
+    gz = str(tmp_path / "p.fq.gz")
+    with gzip.open(gz, "wb", compresslevel=1) as fh:
+        fh.write(raw)
+    assert flatten_file_parallel(gz, 4, 1 << 18) is None
+
+
+def test_block_parallel_ingest_under_tsan(nt, tmp_path):
+    """The ordered-commit machinery (mutex/condvar/atomics, one thread per sink) under ThreadSanitizer, on a strict
+    file and on one that falls back to the sequential reader in the middle; same stream hash for 1 and 8 threads."""
+    import subprocess
+    exe = str(tmp_path / "parallel_tsan")
+    host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
+    srcs = [os.path.join(ROOT, "tools", "parallel_tsan.cpp")] + [os.path.join(host, f) for f in
+            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp")]
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
+    fq = str(tmp_path / "t.fq")
+    s.write_fastq(fq, 0, 12000)
+    lines = open(fq, "rb").read().split(b"\n")
+    lines[24001] = lines[24001][:50] + b"\n" + lines[24001][50:]
+    bad = str(tmp_path / "t_wrapped.fq")
+    open(bad, "wb").write(b"\n".join(lines))
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    for path in (fq, bad):
+        outs = set()
+        for threads, block in ((1, 65536), (8, 65536), (8, 4096), (3, 200_000)):
+            p = subprocess.run([exe, path, str(threads), str(block)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert p.returncode == 0, p.stderr.decode()[-3000:]
+            outs.add(p.stdout.split(b" parallel=")[0] + b" " + p.stdout.split(b" ")[-1])
+        assert len(outs) == 1, outs

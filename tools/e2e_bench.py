@@ -52,3 +52,10 @@ for t in (1, 8):
     p = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", sp, "-t", str(t)] + parts, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     dt = time.perf_counter() - t0
     print("CLI %d files -t %d: %.2f s -> %.3f Gbases/s" % (nf, t, dt, (n_cli // nf) * nf * 150 / dt / 1e9))
+
+# -t N on ONE plain FASTQ: block-parallel ingest (parallel_fastq.hpp)
+for t in (1, 4, 8, 16, 32):
+    t0 = time.perf_counter()
+    p = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", sp, "-t", str(t), fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t0
+    print("CLI single file -t %d: %.2f s -> %.3f Gbases/s" % (t, dt, n_cli * 150 / dt / 1e9))

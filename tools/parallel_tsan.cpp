@@ -1,0 +1,23 @@
+/* Driver for running the block-parallel FASTQ ingest under ThreadSanitizer (tests/test_host_cpu.py):
+ *   parallel_tsan FILE THREADS BLOCK_BYTES  ->  "reads=N bytes=M parallel=P resume=R" */
+#include <cstdio>
+#include <cstdlib>
+
+#include "../include/ntsm_host.h"
+
+int main(int argc, char **argv)
+{
+	if (argc < 4) return 2;
+	uint8_t *bases = nullptr;
+	uint64_t *ends = nullptr, nb = 0, nr = 0, nblk = 0, npar = 0, resume = 0;
+	int rc = ntsm_host_flatten_parallel(argv[1], (unsigned) atoi(argv[2]), strtoull(argv[3], nullptr, 10), &bases, &nb, &ends, &nr,
+			&nblk, &npar, &resume);
+	if (rc) { fprintf(stderr, "rc=%d\n", rc); return 1; }
+	uint64_t h = 1469598103934665603ull;
+	for (uint64_t i = 0; i < nb; ++i) h = (h ^ bases[i]) * 1099511628211ull;
+	printf("reads=%llu bytes=%llu parallel=%llu resume=%llu fnv=%016llx\n", (unsigned long long) nr, (unsigned long long) nb,
+			(unsigned long long) npar, (unsigned long long) resume, (unsigned long long) h);
+	ntsm_host_free(bases);
+	ntsm_host_free(ends);
+	return 0;
+}
