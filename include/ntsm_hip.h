@@ -105,9 +105,12 @@ int ntsm_lane_acquire(ntsm_lane *lane, uint8_t **bases, uint64_t *cap_bytes, uin
 int ntsm_lane_submit(ntsm_lane *lane, uint64_t n_bytes, uint32_t n_reads);
 int ntsm_lane_close(ntsm_lane *lane);
 
-/* Initialise the HIP runtime and the device context of `device` (idempotent, thread-safe): lets a host overlap
- * the ~0.3 s of GPU bring-up with loading the sites file (src/FingerPrint.hpp:489-572) before ntsm_create. */
-int ntsm_warmup(int device);
+/* Initialise the HIP runtime and the device context of `device` and put `n_streams` ready-made streams into the
+ * library's per-device stream pool (contexts take 3, every lane 1; streams go back to the pool when their owner is
+ * destroyed).  Thread-safe.  Creating a stream costs ~14 ms on this runtime, so a host calls this on a side thread
+ * while it loads the sites file (src/FingerPrint.hpp:489-572), before ntsm_create.  Optional: everything is
+ * created on demand otherwise. */
+int ntsm_warmup(int device, int n_streams);
 
 /* Reserve a process-wide pool of `bytes` of pinned host memory that contexts and lanes carve their staging slots
  * from (they fall back to individual allocations when it is exhausted).  Pinning costs ~0.4 ms/MiB and the driver

@@ -63,7 +63,7 @@ _sig(H, "ntsm_lane_open", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTE
 _sig(H, "ntsm_lane_acquire", C.c_int, [C.c_void_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p])
 _sig(H, "ntsm_lane_submit", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32])
 _sig(H, "ntsm_lane_close", C.c_int, [C.c_void_p])
-_sig(H, "ntsm_warmup", C.c_int, [C.c_int])
+_sig(H, "ntsm_warmup", C.c_int, [C.c_int, C.c_int])
 _sig(H, "ntsm_staging_pool", C.c_int, [C.c_uint64])
 _sig(H, "ntsm_count_resident", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int])
 _sig(H, "ntsm_sync", C.c_int, [C.c_void_p, C.POINTER(Totals)])
@@ -325,8 +325,8 @@ class Lane:
             pass
 
 
-def warmup(device=0):
-    _chk(H.ntsm_warmup(device), "ntsm_warmup")
+def warmup(device=0, n_streams=0):
+    _chk(H.ntsm_warmup(device, n_streams), "ntsm_warmup")
 
 
 def staging_pool(n_bytes):

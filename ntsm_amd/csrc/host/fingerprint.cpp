@@ -144,32 +144,39 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 	if (m_opt.devices.empty()) m_opt.devices.push_back(m_opt.device);
 	for (int d : m_opt.devices)
 		if (std::find(m_ctxDevice.begin(), m_ctxDevice.end(), d) == m_ctxDevice.end()) m_ctxDevice.push_back(d);
-	/* GPU bring-up (runtime + device context, ~0.3 s) and the pinning of all staging memory run while this thread
-	 * parses the sites file; the pool is only needed when the first batch is staged (computeCounts). */
+	/* Side threads, one per device, prepare everything that does not depend on the sites while this thread parses
+	 * them: runtime + device context, the three streams of a context, the pinned staging pool (first device),
+	 * one stream per producer lane.  They are joined when the first batch is about to be staged (computeCounts). */
 	const auto tc0 = std::chrono::steady_clock::now();
-	std::vector<std::thread> warm;
-	for (int d : m_ctxDevice) warm.emplace_back([d]() { (void) ntsm_warmup(d); });
 	{
 		const bool maybe_armed = m_opt.covThresh != 0 && m_opt.covThresh < 1e300;
+		const bool lanes = m_opt.threads > 1 && !maybe_armed;
 		const uint64_t slot = std::max<uint64_t>(4096, m_opt.batch_bytes);
-		uint64_t bytes;
-		if (m_opt.threads > 1 && !maybe_armed) bytes = (uint64_t) m_opt.threads * 2 * (std::min<uint64_t>(slot, kLaneBytes) + 8192);
-		else bytes = 2 * (slot + 8192 + (slot / 64 + 16) * 8 + 8192);
-		const int d0 = m_ctxDevice[0];
-		m_poolThread = std::thread([d0, bytes]() { if (ntsm_warmup(d0) == NTSM_OK) (void) ntsm_staging_pool(bytes); });
+		const uint64_t pool_bytes = lanes ? (uint64_t) m_opt.threads * 2 * (std::min<uint64_t>(slot, kLaneBytes) + 8192)
+		                                  : 2 * (slot + 8192 + (slot / 64 + 16) * 8 + 8192);
+		const int lanes_per_dev = lanes ? (int) ((m_opt.threads + m_ctxDevice.size() - 1) / m_ctxDevice.size()) : 0;
+		for (size_t i = 0; i < m_ctxDevice.size(); ++i) {
+			const int d = m_ctxDevice[i];
+			const bool first = i == 0;
+			m_prep.emplace_back([d, first, pool_bytes, lanes_per_dev]() {
+				if (ntsm_warmup(d, 3) != NTSM_OK) return;           /* ntsm_create reports the failure */
+				if (first) (void) ntsm_staging_pool(pool_bytes);
+				(void) ntsm_warmup(d, lanes_per_dev);
+			});
+		}
 	}
 	const bool loaded = m_sites.load(m_opt.snp, m_opt.k, m_opt.dupes, std::cerr);
 	const auto tc1 = std::chrono::steady_clock::now();
-	for (auto &w : warm) w.join();
-	const auto tc2 = std::chrono::steady_clock::now();
 	if (!loaded) {
 		std::cerr << "file " << m_opt.snp << " cannot be opened" << std::endl;   /* :493-499 */
+		joinPrep();                                            /* never exit() under a thread that is inside the HIP runtime */
 		exit(1);
 	}
 	if (m_opt.verbose) std::cerr << "Opening " << m_opt.snp << std::endl;
 	m_maxCounts = threshold_from((double) m_sites.n_distinct(), m_opt.covThresh);
 	if (m_sites.keys.size() > 0xFFFFFFFFull) {
 		std::cerr << "ntsmCount: too many site k-mers" << std::endl;
+		joinPrep();
 		exit(1);
 	}
 	/* one context per distinct device; with -m everything runs on the first one */
@@ -184,24 +191,30 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 		});
 	for (auto &t : mk) t.join();
 	if (m_opt.phase_times)
-		std::cerr << "[phase] sites parsed " << std::chrono::duration<double>(tc1 - tc0).count() << " s, +GPU bring-up wait "
-		          << std::chrono::duration<double>(tc2 - tc1).count() << " s, contexts (tables + upload) "
-		          << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc2).count() << " s" << std::endl;
+		std::cerr << "[phase] sites parsed " << std::chrono::duration<double>(tc1 - tc0).count() << " s, contexts (tables + upload) "
+		          << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc1).count() << " s" << std::endl;
 	for (size_t i = 0; i < rcs.size(); ++i)
 		if (rcs[i]) {
 			std::cerr << "ntsmCount: cannot create GPU context: " << ntsm_strerror(rcs[i]);
 			if (rcs[i] == NTSM_ERR_HIP) std::cerr << " (hipError " << ntsm_last_hip_error() << ")";
 			std::cerr << std::endl;
+			joinPrep();
 			exit(1);
 		}
 }
 
 FingerPrint::~FingerPrint()
 {
-	if (m_poolThread.joinable()) m_poolThread.join();
+	joinPrep();
 	m_main.reset();
 	m_lanes.clear();
 	for (ntsm_ctx *c : m_ctx) ntsm_destroy(c);
+}
+
+void FingerPrint::joinPrep()
+{
+	for (auto &t : m_prep) if (t.joinable()) t.join();
+	m_prep.clear();
 }
 
 Feeder &FingerPrint::feederFor(size_t t)
@@ -229,10 +242,10 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 	 * With -m the reference's parallel schedule is a race; the only defined semantics is
 	 * argv order on one thread, which is what an armed run always uses. */
 	const size_t want = m_maxCounts != 0 ? 1 : std::max(1u, m_opt.threads);
-	if (m_poolThread.joinable()) {
+	if (!m_prep.empty()) {
 		const auto tj = std::chrono::steady_clock::now();
-		m_poolThread.join();
-		if (m_opt.phase_times) std::cerr << "[phase] waited " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tj).count() << " s for the pinned pool" << std::endl;
+		joinPrep();
+		if (m_opt.phase_times) std::cerr << "[phase] waited " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tj).count() << " s for streams + pinned pool" << std::endl;
 	}
 	if (want <= 1) {
 		if (!m_main) m_main.reset(new Feeder(m_opt, m_ctx[0], m_maxCounts, false));

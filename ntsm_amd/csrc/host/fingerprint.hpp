@@ -90,7 +90,8 @@ private:
 	uint64_t m_maxCounts = 0;
 	Feeder &feederFor(size_t t);                         /* thread t's lane on device devices[t % n] (created on first use) */
 	void closeLanes();
-	std::thread m_poolThread;                            /* pins the staging pool while the sites are parsed */
+	void joinPrep();
+	std::vector<std::thread> m_prep;                     /* per device: GPU bring-up, streams, pinned pool while the sites are parsed */
 	std::vector<ntsm_ctx *> m_ctx;                       /* one GPU context per distinct -g device, [0] = first device */
 	std::vector<int> m_ctxDevice;
 	std::unique_ptr<Feeder> m_main;                      /* context [0]'s own staging: single-threaded and -m runs */

@@ -589,6 +589,36 @@ bool pool_free(void *ptr, uint64_t bytes)
 	return true;
 }
 
+/* Process-wide pool of non-blocking HIP streams per device: creating a stream costs ~14 ms and destroying one
+ * ~3 ms on this runtime (tools/api_cost.hip), far more than anything else a lane needs, so streams are recycled
+ * and can be created ahead of time by ntsm_warmup. */
+constexpr int kMaxDevices = 64;
+struct StreamPool {
+	std::mutex mu;
+	std::vector<hipStream_t> idle[kMaxDevices];
+};
+StreamPool g_streams;
+
+hipStream_t stream_get(int device)            /* the calling thread's current device must be `device` */
+{
+	if (device >= 0 && device < kMaxDevices) {
+		std::lock_guard<std::mutex> lk(g_streams.mu);
+		auto &v = g_streams.idle[device];
+		if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+	}
+	hipStream_t s = nullptr;
+	if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+	return s;
+}
+
+void stream_put(int device, hipStream_t s)    /* s must be idle (synchronised) */
+{
+	if (!s) return;
+	if (device < 0 || device >= kMaxDevices) { (void) hipStreamDestroy(s); return; }
+	std::lock_guard<std::mutex> lk(g_streams.mu);
+	g_streams.idle[device].push_back(s);
+}
+
 struct Slot {
 	uint8_t *h_bases = nullptr, *d_bases = nullptr;
 	uint64_t *h_read_end = nullptr, *d_read_end = nullptr;
@@ -839,7 +869,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	return NTSM_OK;
 }
 
-int alloc_slot(Slot &s, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device)
+int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device)
 {
 	s.ends_on_device = ends_on_device;
 	s.h_bases_bytes = cap_bytes + 64;
@@ -855,7 +885,10 @@ int alloc_slot(Slot &s, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_dev
 		if (!s.h_read_end) return NTSM_ERR_NOMEM;
 	}
 	HIPCHK(hipMalloc(&s.d_bases, cap_bytes + 64));
-	if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+	if (!s.stream) {
+		s.stream = stream_get(device);
+		if (!s.stream) return NTSM_ERR_HIP;
+	}
 	if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
 	s.busy = false;
 	s.acquired = false;
@@ -1157,7 +1190,7 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 	if (hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (hipDeviceSynchronize() != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (hipMalloc(&c->d_vec, ((uint64_t) n_kmers + 4) * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
-	if (hipStreamCreateWithFlags(&c->rstream, hipStreamNonBlocking) != hipSuccess) return fail(NTSM_ERR_HIP);
+	if (!(c->rstream = stream_get(device))) return fail(NTSM_ERR_HIP);
 	for (int i = 0; i < kTimingPool; ++i) {
 		if (hipEventCreate(&c->ev_a[i]) != hipSuccess || hipEventCreate(&c->ev_b[i]) != hipSuccess) return fail(NTSM_ERR_HIP);
 	}
@@ -1172,10 +1205,10 @@ void ntsm_destroy(ntsm_ctx *c)
 	(void) hipDeviceSynchronize();
 	for (auto &s : c->slot) {
 		free_slot(s);
-		if (s.stream) (void) hipStreamDestroy(s.stream);
+		stream_put(c->device, s.stream);
 		if (s.done) (void) hipEventDestroy(s.done);
 	}
-	if (c->rstream) (void) hipStreamDestroy(c->rstream);
+	stream_put(c->device, c->rstream);
 	for (int i = 0; i < kTimingPool; ++i) {
 		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
 		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
@@ -1205,7 +1238,7 @@ int ntsm_staging_acquire(ntsm_ctx *c, uint8_t **bases, uint64_t *cap_bytes, uint
 	HIPCHK(hipSetDevice(c->device));
 	Slot &s = c->slot[c->next_slot];
 	if (!s.h_bases) {
-		int rc = alloc_slot(s, c->cap_bytes, c->cap_reads, true);
+		int rc = alloc_slot(s, c->device, c->cap_bytes, c->cap_reads, true);
 		if (rc) return rc;
 	}
 	int rc = wait_slot(s);
@@ -1235,7 +1268,7 @@ int ntsm_submit_staged(ntsm_ctx *c, uint64_t n_bytes, uint32_t n_reads)
 	return rc;
 }
 
-int ntsm_warmup(int device)
+int ntsm_warmup(int device, int n_streams)
 {
 	int n_dev = 0;
 	hipError_t e = hipGetDeviceCount(&n_dev);
@@ -1245,6 +1278,13 @@ int ntsm_warmup(int device)
 	}
 	HIPCHK(hipSetDevice(device));
 	HIPCHK(hipFree(nullptr));                             /* forces runtime + device context initialisation */
+	std::vector<hipStream_t> made;
+	for (int i = 0; i < n_streams && i < 1024; ++i) {
+		hipStream_t s = nullptr;
+		HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+		made.push_back(s);
+	}
+	for (hipStream_t s : made) stream_put(device, s);
 	return NTSM_OK;
 }
 
@@ -1283,14 +1323,18 @@ int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lan
 	l->c = c;
 	l->cap_bytes = cap_bytes;
 	l->cap_reads = cap_reads;
-	for (auto &s : l->slot) {
-		int rc = alloc_slot(s, cap_bytes, cap_reads, false);
+	/* both slots share ONE stream: copy and kernel of a lane's consecutive batches run back to back, the overlap
+	 * comes from the other lanes (a stream is the expensive part of a lane) */
+	for (int i = 0; i < 2; ++i) {
+		Slot &s = l->slot[i];
+		if (i == 1) s.stream = l->slot[0].stream;
+		int rc = alloc_slot(s, c->device, cap_bytes, cap_reads, false);
 		if (rc) {
 			for (auto &q : l->slot) {
 				free_slot(q);
-				if (q.stream) (void) hipStreamDestroy(q.stream);
 				if (q.done) (void) hipEventDestroy(q.done);
 			}
+			stream_put(c->device, l->slot[0].stream);
 			delete l;
 			return rc;
 		}
@@ -1348,12 +1392,12 @@ int ntsm_lane_close(ntsm_lane *l)
 	ntsm_ctx *c = l->c;
 	int rc = NTSM_OK;
 	if (hipSetDevice(c->device) != hipSuccess) rc = NTSM_ERR_HIP;
+	if (l->slot[0].stream && hipStreamSynchronize(l->slot[0].stream) != hipSuccess) rc = NTSM_ERR_HIP;
 	for (auto &s : l->slot) {
-		if (s.stream && hipStreamSynchronize(s.stream) != hipSuccess) rc = NTSM_ERR_HIP;
 		free_slot(s);
-		if (s.stream) (void) hipStreamDestroy(s.stream);
 		if (s.done) (void) hipEventDestroy(s.done);
 	}
+	stream_put(c->device, l->slot[0].stream);
 	{
 		std::lock_guard<std::mutex> lk(c->mu);
 		c->total_bases += l->total_bases;
