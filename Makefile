@@ -28,7 +28,7 @@ build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp 
 	    -Lntsm_amd -lntsm_hip -lz -pthread -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
 ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_device.h include/ntsm_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ntsm_hip.hip -L/opt/rocm/lib -lrccl
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ntsm_hip.hip -ldl
 
 ntsm_amd/libntsm_synth.so: $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp -lz

@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstring>
 
 namespace ntsm {
@@ -97,6 +98,14 @@ bool ParallelFastq::wait_start(size_t b, uint64_t first, uint64_t *prev_end)
 		m_cv.notify_all();
 	}
 	return false;
+}
+
+void ParallelFastq::release(size_t b) const
+{
+	const uint64_t page = 4096;
+	const uint64_t lo = (uint64_t) b * m_block, hi = std::min(m_size, lo + m_block);
+	const uint64_t a = (lo + page - 1) & ~(page - 1), z = hi & ~(page - 1);
+	if (z > a) (void) madvise(const_cast<char *>(m_data) + a, z - a, MADV_DONTNEED);
 }
 
 void ParallelFastq::publish(size_t b, uint64_t end)

@@ -70,7 +70,10 @@ public:
 		for (Sink *s : sinks)
 			pool.emplace_back([this, s, &records]() {
 				uint64_t n = 0;
-				for (size_t b = m_next++; b < m_nBlocks; b = m_next++) n += work<Sink>(*s, b);
+				for (size_t b = m_next++; b < m_nBlocks; b = m_next++) {
+					n += work<Sink>(*s, b);
+					release(b);
+				}
 				records += n;
 			});
 		for (auto &t : pool) t.join();
@@ -93,6 +96,9 @@ private:
 	bool wait_start(size_t b, uint64_t first, uint64_t *prev_end);
 	void publish(size_t b, uint64_t end);
 	void fail(size_t b, uint64_t resume);
+	/* drop block b's page-table entries (the page cache keeps the data): spreads the teardown of a multi-GB
+	 * mapping over the worker threads instead of paying it single-threaded in munmap */
+	void release(size_t b) const;
 
 	template <class Sink> uint64_t work(Sink &s, size_t b)
 	{

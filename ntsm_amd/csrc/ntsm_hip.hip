@@ -18,7 +18,8 @@
  * There is no CPU fallback anywhere in this file.
  */
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>                     /* types only: the library is bound with dlopen in ntsm_allreduce */
 
 #include <algorithm>
 #include <cstdint>
@@ -1605,21 +1606,45 @@ int ntsm_allreduce(ntsm_ctx *const *ctxs, int n)
 		if (rc) return rc;
 	}
 	if (n > 1) {
+		/* RCCL is bound on first use: the library is 570 MB of code objects that the HIP runtime would otherwise
+		 * map and register in every process that links it (≈0.1 s and 1.4 GB of RSS for a single-GPU ntsmCount). */
+		struct Rccl {
+			decltype(&ncclCommInitAll) CommInitAll = nullptr;
+			decltype(&ncclGroupStart) GroupStart = nullptr;
+			decltype(&ncclGroupEnd) GroupEnd = nullptr;
+			decltype(&ncclAllReduce) AllReduce = nullptr;
+			decltype(&ncclCommDestroy) CommDestroy = nullptr;
+			bool ok = false;
+			Rccl()
+			{
+				void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+				if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+				if (!h) return;
+				CommInitAll = (decltype(CommInitAll)) dlsym(h, "ncclCommInitAll");
+				GroupStart = (decltype(GroupStart)) dlsym(h, "ncclGroupStart");
+				GroupEnd = (decltype(GroupEnd)) dlsym(h, "ncclGroupEnd");
+				AllReduce = (decltype(AllReduce)) dlsym(h, "ncclAllReduce");
+				CommDestroy = (decltype(CommDestroy)) dlsym(h, "ncclCommDestroy");
+				ok = CommInitAll && GroupStart && GroupEnd && AllReduce && CommDestroy;
+			}
+		};
+		static Rccl rccl;                                     /* thread-safe one-time binding */
+		if (!rccl.ok) return NTSM_ERR_RCCL;
 		std::vector<int> devs(n);
 		std::vector<ncclComm_t> comms(n);
 		for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
-		if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) return NTSM_ERR_RCCL;
-		bool ok = ncclGroupStart() == ncclSuccess;
+		if (rccl.CommInitAll(comms.data(), n, devs.data()) != ncclSuccess) return NTSM_ERR_RCCL;
+		bool ok = rccl.GroupStart() == ncclSuccess;
 		for (int i = 0; i < n && ok; ++i) {
 			ok = hipSetDevice(devs[i]) == hipSuccess &&
-				ncclAllReduce(ctxs[i]->d_vec, ctxs[i]->d_vec, (size_t) ctxs[i]->n_kmers + 4, ncclUint64, ncclSum,
+				rccl.AllReduce(ctxs[i]->d_vec, ctxs[i]->d_vec, (size_t) ctxs[i]->n_kmers + 4, ncclUint64, ncclSum,
 						comms[i], ctxs[i]->rstream) == ncclSuccess;
 		}
-		ok = (ncclGroupEnd() == ncclSuccess) && ok;
+		ok = (rccl.GroupEnd() == ncclSuccess) && ok;
 		for (int i = 0; i < n; ++i) {
 			(void) hipSetDevice(devs[i]);
 			(void) hipStreamSynchronize(ctxs[i]->rstream);
-			ncclCommDestroy(comms[i]);
+			rccl.CommDestroy(comms[i]);
 		}
 		if (!ok) return NTSM_ERR_RCCL;
 	}
