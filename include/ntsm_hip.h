@@ -137,6 +137,13 @@ int ntsm_counts_device(ntsm_ctx *ctx, void **d_vec, uint64_t *n_words);
 int ntsm_import_reduced(ntsm_ctx *ctx);
 /* Single-process multi-GPU merge: RCCL SUM over the n contexts' count vectors + totals (xGMI). */
 int ntsm_allreduce(ntsm_ctx *const *ctxs, int n);
+/* Re-arm or disarm the -m stop of a context.  The threshold is compared (strict '>', after every whole read) with
+ * the context's OWN cumulative total_hits, so a caller that orders reads across several contexts passes
+ * total_hits_of_this_context + (global threshold - hits counted globally before the next batch); see
+ * ntsm_amd/dist.py OrderedEarlyStop for the multi-GPU protocol built on it (the reference's stop,
+ * src/FingerPrint.hpp:473-488, is single-process).  armed = 0: batches are counted without the check (max_hits is
+ * ignored); armed = 1 with max_hits = 0 stops after the first read that has a hit.  Does not clear early_stop. */
+int ntsm_set_max_hits(ntsm_ctx *ctx, uint64_t max_hits, int armed);
 /* Forget all counts and totals (table stays). */
 int ntsm_reset(ntsm_ctx *ctx);
 

@@ -72,6 +72,7 @@ _sig(H, "ntsm_counts_device", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), u64p]
 _sig(H, "ntsm_import_reduced", C.c_int, [C.c_void_p])
 _sig(H, "ntsm_allreduce", C.c_int, [C.POINTER(C.c_void_p), C.c_int])
 _sig(H, "ntsm_reset", C.c_int, [C.c_void_p])
+_sig(H, "ntsm_set_max_hits", C.c_int, [C.c_void_p, C.c_uint64, C.c_int])
 _sig(H, "ntsm_set_timing", C.c_int, [C.c_void_p, C.c_int])
 _sig(H, "ntsm_get_timing", C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_double)])
 _sig(H, "ntsm_set_tuning", C.c_int, [C.c_void_p, C.c_int, C.c_int])
@@ -234,6 +235,9 @@ class Context:
     def open_lane(self, cap_bytes=0, cap_reads=0):
         """A producer lane (ntsm_lane_*): one host thread's private staging into this context."""
         return Lane(self, cap_bytes, cap_reads)
+
+    def set_max_hits(self, max_hits, armed=True):
+        _chk(H.ntsm_set_max_hits(self._h, int(max_hits), int(bool(armed))), "ntsm_set_max_hits")
 
     def set_batch_capacity(self, cap_bytes, cap_reads):
         _chk(H.ntsm_set_batch_capacity(self._h, cap_bytes, cap_reads), "ntsm_set_batch_capacity")

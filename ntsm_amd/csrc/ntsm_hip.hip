@@ -662,6 +662,7 @@ struct ntsm_ctx {
 	int device = 0, k = 0;
 	uint32_t n_kmers = 0;
 	uint64_t max_hits = 0;
+	bool armed = false;                        /* the -m stop is active (max_hits != 0 at creation, or ntsm_set_max_hits) */
 	uint64_t mask = 0;
 	/* device tables */
 	uint32_t *d_filter = nullptr, *d_slot_of = nullptr, *d_read_hits = nullptr;
@@ -1072,7 +1073,7 @@ int submit_slot(ntsm_ctx *c, Slot &s, uint64_t n_bytes, uint32_t n_reads)
 {
 	if (n_reads == 0) return NTSM_OK;
 	HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, n_bytes, hipMemcpyHostToDevice, s.stream));
-	if (c->max_hits) {
+	if (c->armed) {
 		HIPCHK(hipMemcpyAsync(s.d_read_end, s.h_read_end, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
 		return armed_batch(c, s.stream, s.d_bases, n_bytes, s.d_read_end, s.h_read_end, n_reads);
 	}
@@ -1162,6 +1163,7 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 	c->k = k;
 	c->n_kmers = n_kmers;
 	c->max_hits = max_hits;
+	c->armed = max_hits != 0;
 	c->mask = mask_for_k(k);
 	memset(c->ev_used, 0, sizeof c->ev_used);
 	hipDeviceProp_t prop;
@@ -1314,7 +1316,7 @@ int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lan
 {
 	if (!c || !out) return NTSM_ERR_ARG;
 	*out = nullptr;
-	if (c->max_hits) return NTSM_ERR_STATE;               /* -m is defined on ONE ordered stream of reads */
+	if (c->armed) return NTSM_ERR_STATE;                  /* -m is defined on ONE ordered stream of reads */
 	if (cap_bytes == 0) cap_bytes = c->cap_bytes;
 	if (cap_reads == 0) cap_reads = cap_bytes / 64 + 16;
 	if (cap_bytes < 4096 || cap_reads < 16) return NTSM_ERR_ARG;
@@ -1436,7 +1438,7 @@ int ntsm_count_resident(ntsm_ctx *c, const void *d_bases, uint64_t n_bytes, cons
 	if (c->early_stop) return NTSM_OK;
 	c->reduced = false;
 	HIPCHK(hipSetDevice(c->device));
-	if (c->max_hits && sign > 0) {
+	if (c->armed && sign > 0) {
 		if (!d_read_end) return NTSM_ERR_ARG;
 		return armed_batch(c, c->rstream, (const uint8_t *) d_bases, n_bytes, (const uint64_t *) d_read_end, nullptr, n_reads);
 	}
@@ -1533,6 +1535,16 @@ int ntsm_reset(ntsm_ctx *c)
 	HIPCHK(hipStreamSynchronize(c->rstream));
 	c->total_bases = c->reads_consumed = 0;
 	c->early_stop = c->reduced = false;
+	return NTSM_OK;
+}
+
+int ntsm_set_max_hits(ntsm_ctx *c, uint64_t max_hits, int armed)
+{
+	if (!c) return NTSM_ERR_ARG;
+	int rc = ntsm_sync(c, nullptr);                       /* also refuses while lanes are open */
+	if (rc) return rc;
+	c->max_hits = max_hits;
+	c->armed = armed != 0;
 	return NTSM_OK;
 }
 

@@ -36,3 +36,101 @@ def merge_counts(ctx, group=None):
     allreduce_sum_(vec, group)
     torch.cuda.synchronize()
     ctx.import_reduced()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Ordered -m early stop across ranks (SURVEY.md section 8(f) item 2)
+#
+# The reference stops after the first read at which the cumulative number of site-k-mer hits exceeds
+# m_maxCounts (src/FingerPrint.hpp:473-488: checked after every whole read, strict '>'); which read that is
+# depends on the order of the reads, so a multi-GPU run has to fix one.  Here the global order is: super-batch
+# 0, 1, 2, ...; inside a super-batch rank 0's shard, then rank 1's, ...  Per super-batch:
+#   1. every rank counts its shard WITHOUT the check and notes the hits it added            (no waiting)
+#   2. one all-gather of those W integers
+#   3. no crossing (hits so far + sum <= max): done.  Otherwise r* = first rank whose inclusive prefix exceeds
+#      max: ranks > r* take their shard out again (sign = -1, exact), rank r* takes its shard out and counts it
+#      again ARMED with the budget that was left when its shard began -- the library finds the exact read --,
+#      ranks < r* keep theirs.  Everybody stops.
+# The result (counts, totals, number of reads consumed) equals one context consuming the same reads in the same
+# order with the same threshold; the cost without a crossing is one tiny all-gather per super-batch.
+# ---------------------------------------------------------------------------------------------------------
+def all_gather_int(value, group=None):
+    """[value of rank 0, rank 1, ...] (non-negative integers below 2^63)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [int(value)]
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return [int(t.item()) for t in out]
+
+
+class ContextEngine:
+    """The three operations OrderedEarlyStop needs, on a GPU context.  A shard is (d_bases_ptr, n_bytes,
+    d_read_end_ptr, n_reads): a flat stream resident in device memory (include/ntsm_hip.h)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def count(self, shard):
+        ptr, n_bytes, ends, n_reads = shard
+        before = self.ctx.sync().total_hits
+        self.ctx.set_max_hits(0, armed=False)
+        self.ctx.count_resident(ptr, n_bytes, ends, n_reads, 1)
+        return self.ctx.sync().total_hits - before
+
+    def undo(self, shard):
+        ptr, n_bytes, ends, n_reads = shard
+        self.ctx.count_resident(ptr, n_bytes, ends, n_reads, -1)
+
+    def recount_armed(self, shard, budget):
+        """Count the shard again, stopping after the first read at which the shard's own hits exceed budget;
+        returns the number of reads consumed."""
+        ptr, n_bytes, ends, n_reads = shard
+        t0 = self.ctx.sync()
+        self.ctx.set_max_hits(t0.total_hits + budget, armed=True)
+        self.ctx.count_resident(ptr, n_bytes, ends, n_reads, 1)
+        return self.ctx.sync().reads_consumed - t0.reads_consumed
+
+
+class OrderedEarlyStop:
+    """Deterministic global -m stop for reads sharded over ranks; see the protocol above.  `all_gather` maps this
+    rank's integer to the list over ranks (default: torch.distributed); `engine` is a ContextEngine or anything
+    with the same three methods (tests use a CPU engine)."""
+
+    def __init__(self, engine, max_hits, rank=0, all_gather=None, group=None):
+        self.engine, self.max_hits, self.rank = engine, int(max_hits), rank
+        self.all_gather = all_gather if all_gather is not None else (lambda v: all_gather_int(v, group))
+        self.hits_before = 0              # hits counted globally in the super-batches consumed so far
+        self.stopped = False
+        self.stop_rank = None
+        self.reads_consumed = 0           # by this rank
+
+    def step(self, shard, n_reads):
+        """Consume one super-batch (this rank's shard of it).  Returns True once the threshold has tripped;
+        later calls are ignored like reads after the stop in the reference (src/FingerPrint.hpp:66)."""
+        if self.stopped:
+            return True
+        mine = self.engine.count(shard) if n_reads else 0
+        per_rank = self.all_gather(mine)
+        total = self.hits_before + sum(per_rank)
+        if total <= self.max_hits:                       # strict '>' like the reference
+            self.hits_before = total
+            self.reads_consumed += n_reads
+            return False
+        acc = self.hits_before
+        for r, h in enumerate(per_rank):
+            if acc + h > self.max_hits:
+                self.stop_rank = r
+                break
+            acc += h
+        if self.rank < self.stop_rank:
+            self.reads_consumed += n_reads
+        elif self.rank > self.stop_rank:
+            if n_reads:
+                self.engine.undo(shard)
+        else:
+            self.engine.undo(shard)
+            self.reads_consumed += self.engine.recount_armed(shard, self.max_hits - acc)
+        self.stopped = True
+        return True

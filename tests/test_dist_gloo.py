@@ -65,3 +65,105 @@ def test_two_rank_sum_merge_equals_single_run(built):
     sites = ntsm_amd.Sites(os.path.join(G, "sites200.fa"))
     rc, text = sites.format_counts(merged[:-4], int(merged[-4]))
     assert rc == 0 and text == open(os.path.join(ROOT, "tests", "golden", "expected", "tiny_k19.stdout"), "rb").read()
+
+
+# ---- ordered -m stop across ranks (ntsm_amd.dist.OrderedEarlyStop) on CPU: the protocol with the oracle as engine ----
+class _OracleEngine:
+    """count / undo / recount_armed of ntsm_amd.dist.ContextEngine, done with the CPU oracle (tests only)."""
+
+    def __init__(self, sites_path):
+        from oracle_binding import OracleFP
+        self.OracleFP, self.sites_path = OracleFP, sites_path
+        self.vec, self.tot, self.last = None, np.zeros(3, dtype=np.int64), None
+
+    def _run(self, shard, budget=None):
+        bases, ends = shard
+        fp = self.OracleFP(self.sites_path)
+        buf, start, n = bases.tobytes(), 0, 0
+        for e in ends.tolist():
+            fp.process(buf[start:e])
+            start, n = e + 1, n + 1
+            if budget is not None and fp.total_hits > budget:
+                break
+        return fp.kmers()[2].astype(np.int64), np.array([fp.total_kmers, fp.total_hits, fp.total_bases], dtype=np.int64), n
+
+    def _add(self, v, t, sign):
+        self.vec = sign * v if self.vec is None else self.vec + sign * v
+        self.tot = self.tot + sign * t
+
+    def count(self, shard):
+        v, t, _ = self._run(shard)
+        self.last = (v, t)
+        self._add(v, t, 1)
+        return int(t[1])
+
+    def undo(self, shard):
+        self._add(self.last[0], self.last[1], -1)
+
+    def recount_armed(self, shard, budget):
+        v, t, n = self._run(shard, budget)
+        self._add(v, t, 1)
+        return n
+
+
+def _slice(bases, ends, lo, hi):
+    if hi <= lo:
+        return (bases[:0], ends[:0])
+    start = 0 if lo == 0 else int(ends[lo - 1]) + 1
+    return (bases[start:int(ends[hi - 1]) + 1], ends[lo:hi] - np.uint64(start))
+
+
+def _ordered_worker(rank, world, port, max_hits, per_super, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ntsm_amd
+    from ntsm_amd.dist import OrderedEarlyStop, allreduce_sum_, shard_range
+    bases, ends, _ = ntsm_amd.flatten_file(os.path.join(G, "reads2k.fq"))
+    eng = _OracleEngine(os.path.join(G, "sites200.fa"))
+    stop = OrderedEarlyStop(eng, max_hits, rank=rank)
+    for s0 in range(0, len(ends), per_super):
+        n_sb = min(per_super, len(ends) - s0)
+        lo, hi = shard_range(n_sb, rank, world)
+        if stop.step(_slice(bases, ends, s0 + lo, s0 + hi), hi - lo):
+            break
+    vec = eng.vec if eng.vec is not None else np.zeros(1, dtype=np.int64)
+    out = torch.from_numpy(np.concatenate([vec, eng.tot, np.array([stop.reads_consumed], dtype=np.int64)]).copy())
+    allreduce_sum_(out)
+    if rank == 0:
+        q.put((out.numpy().copy(), stop.stopped, stop.stop_rank))
+    dist.destroy_process_group()
+
+
+def test_ordered_early_stop_across_ranks_equals_single_run(built):
+    """Three gloo ranks, reads in super-batches of 250 split over the ranks: the global -m stop lands on the same read,
+    with the same counts and totals, as one reference-equivalent run over the reads in the same order."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleFP
+    import ntsm_amd
+    from ntsm_amd.dist import shard_range
+    bases, ends, _ = ntsm_amd.flatten_file(os.path.join(G, "reads2k.fq"))
+    world, per_super = 3, 250
+    # the order the protocol defines: super-batch by super-batch, rank shards in rank order == file order here
+    full = OracleFP(os.path.join(G, "sites200.fa"))
+    full.process_flat(bases, ends)
+    for frac in (0.37, 0.5, 0.93):
+        target = int(full.total_hits * frac)
+        ref = OracleFP(os.path.join(G, "sites200.fa"), cov=2.0 * (target + 0.5) / full.n_distinct)
+        assert ref.max_hits == target
+        ref.process_flat(bases, ends)
+        assert ref.early_term and 0 < ref.reads_processed < len(ends)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 31500 + (os.getpid() + int(frac * 100)) % 2000
+        procs = [ctx.Process(target=_ordered_worker, args=(r, world, port, target, per_super, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        merged, stopped, stop_rank = q.get(timeout=180)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert stopped and stop_rank is not None
+        assert np.array_equal(merged[:-4].astype(np.uint64), ref.kmers()[2])
+        assert list(merged[-4:]) == [ref.total_kmers, ref.total_hits, ref.total_bases, ref.reads_processed]

@@ -412,6 +412,85 @@ def test_early_stop_across_chunks(nt, n10):
     ctx.close()
 
 
+def test_ordered_early_stop_over_several_contexts(nt, n10):
+    """ntsm_amd.dist.OrderedEarlyStop with ContextEngine: three contexts (stand-ins for three GPUs/ranks, driven by
+    three threads with a barrier all-gather) consume super-batches split in rank order; the global -m stop equals one
+    armed context -- and the oracle -- on the same reads: same read, counts and totals.  Also ntsm_set_max_hits."""
+    import threading
+    import torch
+    from ntsm_amd.dist import ContextEngine, OrderedEarlyStop, shard_range
+    s, sites, path = n10
+    n, world, per_super = 576_000, 3, 96_000        # shards of 32,000 reads: device pointers stay 16-byte aligned
+    dev = torch.device("cuda:0")
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d_bases = torch.empty(n * s.stride, dtype=torch.uint8, device=dev)
+    s.device_fill(d_win.data_ptr(), 0, n, d_bases.data_ptr())
+    torch.cuda.synchronize()
+    probe = nt.Context(sites.keys)
+    probe.count_resident(d_bases.data_ptr(), n * s.stride, 0, n)
+    all_hits = probe.sync().total_hits
+    probe.close()
+    for frac in (0.41, 0.08):
+        thr = int(all_hits * frac)
+        fp = OracleFP(path, cov=2.0 * (thr + 0.5) / len(sites.keys))
+        assert fp.max_hits == thr
+        fp.process_flat(s.host_bytes(0, n), s.read_end(n))
+        assert fp.early_term
+        ctxs = [nt.Context(sites.keys) for _ in range(world)]
+        barrier, box = threading.Barrier(world), [0] * world
+        stops, errs = [None] * world, []
+
+        def run(rank):
+            try:
+                def all_gather(v):
+                    box[rank] = v
+                    barrier.wait()
+                    out = list(box)
+                    barrier.wait()
+                    return out
+                st = OrderedEarlyStop(ContextEngine(ctxs[rank]), thr, rank=rank, all_gather=all_gather)
+                stops[rank] = st
+                for s0 in range(0, n, per_super):
+                    lo, hi = shard_range(per_super, rank, world)
+                    nr = hi - lo
+                    ends = torch.from_numpy(s.read_end(nr).view(np.int64)).to(dev)     # shard-relative terminators
+                    torch.cuda.synchronize()
+                    shard = (d_bases.data_ptr() + (s0 + lo) * s.stride, nr * s.stride, ends.data_ptr(), nr)
+                    if st.step(shard, nr):
+                        break
+            except Exception as e:                            # pragma: no cover
+                errs.append(e)
+                barrier.abort()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        assert not errs, errs
+        assert all(st.stopped for st in stops) and len({st.stop_rank for st in stops}) == 1
+        tot = [c.sync() for c in ctxs]
+        counts = sum(c.counts() for c in ctxs)
+        assert sum(st.reads_consumed for st in stops) == fp.reads_processed == sum(t.reads_consumed for t in tot)
+        assert (sum(t.total_kmers for t in tot), sum(t.total_hits for t in tot), sum(t.total_bases for t in tot)) == \
+            (fp.total_kmers, fp.total_hits, fp.total_bases)
+        assert np.array_equal(counts, fp.kmers()[2])
+        assert tot[stops[0].stop_rank].early_stop == 1
+        [c.close() for c in ctxs]
+    # ntsm_set_max_hits on its own: armed with threshold 0 stops after the first read that has a hit
+    c = nt.Context(sites.keys)
+    c.set_max_hits(0, armed=True)
+    ends = torch.from_numpy(s.read_end(50_000).view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    c.count_resident(d_bases.data_ptr(), 50_000 * s.stride, ends.data_ptr(), 50_000)
+    t = c.sync()
+    fp0 = OracleFP(path)
+    buf = s.host_bytes(0, 50_000).tobytes()
+    k = 0
+    while fp0.total_hits == 0:
+        fp0.process(buf[k * s.stride:k * s.stride + s.read_len])
+        k += 1
+    assert t.early_stop == 1 and t.reads_consumed == k and t.total_hits == fp0.total_hits
+    c.close()
+
+
 def test_cli_threads_over_files(nt, tmp_path):
     """-t N counts N files at a time (the reference's omp-over-files, src/FingerPrint.hpp:47), each host thread with
     its own GPU context; the summed result is the single-thread bytes.  With -m the run stays on one thread."""
