@@ -13,14 +13,15 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wextra -Wno-unuse
 CSRC     := ntsm_amd/csrc
 
 HOST     := $(CSRC)/host
-HOSTSRC  := $(HOST)/seq_reader.cpp $(HOST)/site_set.cpp $(HOST)/report.cpp $(HOST)/parallel_fastq.cpp
+HOSTSRC  := $(HOST)/seq_reader.cpp $(HOST)/site_set.cpp $(HOST)/report.cpp $(HOST)/parallel_fastq.cpp \
+            $(HOST)/inflate.cpp $(HOST)/gz_stream.cpp $(HOST)/crc32_fast.cpp
 HOSTHDR  := $(wildcard $(HOST)/*.hpp) include/ntsm_host.h include/ntsm_hip.h
 
 all: oracle_all build/ntsm_synth build/gather_bench ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount
 
 # host-only pieces (reader, site loader, report formatting): no HIP dependency
 ntsm_amd/libntsm_host.so: $(HOSTSRC) $(HOST)/host_capi.cpp $(HOSTHDR)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC) $(HOST)/host_capi.cpp -lz
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC) $(HOST)/host_capi.cpp -lz -pthread
 
 build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp $(HOSTHDR) ntsm_amd/libntsm_hip.so
 	@mkdir -p build

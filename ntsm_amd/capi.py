@@ -94,6 +94,7 @@ _sig(HO, "ntsm_sites_n_erased", C.c_uint64, [C.c_void_p])
 _sig(HO, "ntsm_host_max_hits", C.c_uint64, [C.c_uint64, C.c_double])
 _sig(HO, "ntsm_host_flatten", C.c_int, [C.c_char_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, C.POINTER(C.c_int)])
 _sig(HO, "ntsm_host_free", None, [C.c_void_p])
+_sig(HO, "ntsm_host_gunzip", C.c_int, [C.c_char_p, C.c_int, C.c_uint, C.POINTER(u8p), u64p])
 _sig(HO, "ntsm_host_flatten_parallel", C.c_int, [C.c_char_p, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, u64p])
 _sig(HO, "ntsm_host_format_counts", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)])
 _sig(HO, "ntsm_host_format_summary", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -186,6 +187,17 @@ def flatten_file(path):
     HO.ntsm_host_free(b)
     HO.ntsm_host_free(e)
     return bases, ends, rc.value
+
+
+def gunzip(path, engine=0, chunk=1 << 16):
+    """(bytes delivered, final status) of the gzip decoder thread (engine 0) or zlib's gzread (engine 1)."""
+    b, n = u8p(), C.c_uint64()
+    rc = HO.ntsm_host_gunzip(os.fsencode(path), engine, chunk, C.byref(b), C.byref(n))
+    if rc == -2:
+        raise NtsmError("cannot open %s" % path)
+    data = C.string_at(b, n.value)
+    HO.ntsm_host_free(b)
+    return data, rc
 
 
 def flatten_file_parallel(path, n_threads=4, block_bytes=1 << 20):

@@ -1,0 +1,65 @@
+/*
+ * gz_stream.hpp -- gzip input for the sequence reader: a decoder thread inflates the (memory-mapped) file with
+ * ntsm::Inflate and hands 1 MiB pieces of text to the parsing thread, which also checks each member's CRC-32 and
+ * length.  Replaces gzread (src/FingerPrint.hpp:27 instantiates kseq over it) for files that start with the gzip
+ * magic; the call semantics follow gzread as kseq uses it: read() returns the number of bytes (> 0), 0 at the end
+ * of the data -- also when the file is truncated inside a member, like gzread, which reports Z_BUF_ERROR only
+ * through gzerror() --, -1 on invalid data (bad header, corrupt deflate stream, CRC or length mismatch).
+ * Concatenated members are decoded back to back; anything after the last member that does not start with the
+ * gzip magic is ignored (zlib gz_look: "trailing garbage").
+ */
+#ifndef NTSM_GZ_STREAM_HPP
+#define NTSM_GZ_STREAM_HPP
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace ntsm {
+
+class GzStream {
+public:
+	GzStream() = default;
+	~GzStream() { close(); }
+	GzStream(const GzStream &) = delete;
+	GzStream &operator=(const GzStream &) = delete;
+
+	static bool is_gzip(const std::string &path);      /* regular file that starts with 1f 8b */
+	bool open(const std::string &path);
+	int read(void *dst, unsigned len);
+	void close();
+
+private:
+	struct Piece {
+		std::vector<uint8_t> data;
+		size_t len = 0;
+		bool member_end = false;                       /* after these bytes a member ends: check crc / isize */
+		uint32_t crc = 0, isize = 0;
+		int status = 0;                                /* after these bytes: 0 = more, 1 = end of data, -1 = error */
+	};
+	void produce();
+	bool push(std::unique_ptr<Piece> p);               /* false: reader went away */
+	std::unique_ptr<Piece> blank();
+
+	const uint8_t *m_map = nullptr;
+	size_t m_size = 0;
+	int m_fd = -1;
+	std::thread m_thread;
+	std::mutex m_mu;
+	std::condition_variable m_cv;
+	std::deque<std::unique_ptr<Piece>> m_ready, m_free;
+	bool m_stop = false;
+	/* reader side */
+	std::unique_ptr<Piece> m_cur;
+	size_t m_off = 0;
+	uint32_t m_crc = 0;
+	uint64_t m_len = 0;
+	int m_final = 0;                                   /* 1 / -1 once the end / an error has been reached */
+};
+
+} // namespace ntsm
+#endif

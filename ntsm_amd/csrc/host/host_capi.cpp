@@ -6,6 +6,9 @@
 #include <sstream>
 
 #include <algorithm>
+#include <zlib.h>
+
+#include "gz_stream.hpp"
 #include "parallel_fastq.hpp"
 #include "report.hpp"
 #include "seq_reader.hpp"
@@ -73,6 +76,26 @@ int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint
 }
 
 void ntsm_host_free(void *p) { free(p); }
+
+int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out, uint64_t *len)
+{
+	std::vector<uint8_t> all, buf(chunk ? chunk : 1);
+	int r;
+	if (engine == 0) {
+		ntsm::GzStream gz;
+		if (!gz.open(path)) return -2;
+		while ((r = gz.read(buf.data(), (unsigned) buf.size())) > 0) all.insert(all.end(), buf.begin(), buf.begin() + r);
+	} else {
+		gzFile f = gzopen(path, "r");
+		if (!f) return -2;
+		while ((r = gzread(f, buf.data(), (unsigned) buf.size())) > 0) all.insert(all.end(), buf.begin(), buf.begin() + r);
+		gzclose(f);
+	}
+	*out = (uint8_t *) malloc(all.size() + 1);
+	memcpy(*out, all.data(), all.size());
+	*len = all.size();
+	return r;
+}
 
 namespace {
 /* Test sink of the block-parallel ingest: a small "staging" buffer whose flushes are kept as (block, order) chunks */

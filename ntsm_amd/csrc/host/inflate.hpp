@@ -1,0 +1,62 @@
+/*
+ * inflate.hpp -- DEFLATE (RFC 1951) decoder for the gzip ingest path.
+ *
+ * The reference reads every input through zlib's gzread (src/FingerPrint.hpp:27, vendor/kseq.h:75-85).  zlib
+ * 1.2.11 inflates FASTQ text at 0.2-0.4 GB/s, an order of magnitude below the parser, so a gzipped input is bound
+ * by inflate alone.  This decoder is written for that one job: the whole compressed file is in memory (mmap), so
+ * there is no input refill logic; a 64-bit bit buffer is topped up with one unaligned load; literal/length symbols
+ * resolve through an 11-bit table (distance: 8-bit) with sub-tables for longer codes; matches are copied 8 bytes
+ * at a time.  It accepts exactly the streams zlib's inflate accepts and fails (DATA_ERROR) on the ones it rejects
+ * (over-subscribed or incomplete code sets other than a single one-bit code, missing end-of-block code, too many
+ * length/distance symbols, distances beyond the start of the member or the 32 KiB window, stored-length mismatch).
+ * Test infrastructure compares it with zlib on every gzip input of the test-suite and on fuzzed streams
+ * (tests/test_host_cpu.py).
+ */
+#ifndef NTSM_INFLATE_HPP
+#define NTSM_INFLATE_HPP
+#include <cstddef>
+#include <cstdint>
+
+namespace ntsm {
+
+class Inflate {
+public:
+	enum Status {
+		MORE,          /* stopped because the output position reached out_stop; call again */
+		STREAM_END,    /* the final block ended; in() is the first byte after the deflate stream (byte aligned) */
+		TRUNCATED,     /* the input ended inside the stream; everything decodable has been written */
+		DATA_ERROR     /* invalid stream */
+	};
+
+	/* Start a new deflate stream at [in, in_end).  `window` = number of bytes before the current output position
+	 * that belong to this stream (0 at the start of a gzip member). */
+	void reset(const uint8_t *in, const uint8_t *in_end);
+
+	/* Decode into buf (the bytes [0, *out) already hold this stream's history as far as it exists) until *out >=
+	 * out_stop or the stream ends.  A call may write up to 258 + 8 bytes past out_stop. */
+	Status run(uint8_t *buf, size_t *out, size_t out_stop);
+
+	const uint8_t *in() const;          /* next unread input byte (valid after STREAM_END: bit buffer returned) */
+	uint64_t total_out() const { return m_total; }   /* bytes produced since reset() */
+
+private:
+	static constexpr int kLitBits = 11, kDistBits = 8;
+	static constexpr int kLitSize = (1 << kLitBits) + 1024, kDistSize = (1 << kDistBits) + 512;
+	enum Mode { HEADER, STORED, HUFFMAN, DONE };
+	bool build(uint32_t *table, int table_bits, int max_size, const uint8_t *lens, int n, bool is_dist);
+	bool read_dynamic_header();
+	void set_fixed();
+	Status run_huffman(uint8_t *buf, size_t *out, size_t out_stop);
+
+	const uint8_t *m_in = nullptr, *m_end = nullptr;
+	uint64_t m_bb = 0;
+	unsigned m_bc = 0;
+	Mode m_mode = HEADER;
+	bool m_last = false;
+	uint32_t m_stored = 0;
+	uint64_t m_total = 0;
+	uint32_t m_lit[kLitSize], m_dist[kDistSize];
+};
+
+} // namespace ntsm
+#endif

@@ -1,6 +1,7 @@
 #include "seq_reader.hpp"
 
 #include <cctype>
+#include <cstdlib>
 #include <cstring>
 
 namespace ntsm {
@@ -8,10 +9,15 @@ namespace ntsm {
 bool SeqReader::open(const std::string &path, uint64_t offset)
 {
 	close();
-	f_ = gzopen(path.c_str(), "r");
-	if (!f_) return false;
-	gzbuffer(f_, 1 << 20);
-	if (offset && gzseek(f_, (z_off_t) offset, SEEK_SET) < 0) { close(); return false; }
+	if (offset == 0 && !getenv("NTSM_ZLIB_ONLY") && GzStream::is_gzip(path)) {
+		gz_.reset(new GzStream());
+		if (!gz_->open(path)) { gz_.reset(); return false; }
+	} else {
+		f_ = gzopen(path.c_str(), "r");
+		if (!f_) return false;
+		gzbuffer(f_, 1 << 20);
+		if (offset && gzseek(f_, (z_off_t) offset, SEEK_SET) < 0) { close(); return false; }
+	}
 	buf_.resize(kBuf);
 	beg_ = end_ = 0;
 	eof_ = false;
@@ -19,16 +25,22 @@ bool SeqReader::open(const std::string &path, uint64_t offset)
 	return true;
 }
 
+int SeqReader::source_read(void *dst, unsigned len)
+{
+	return gz_ ? gz_->read(dst, len) : gzread(f_, dst, len);
+}
+
 void SeqReader::close()
 {
 	if (f_) gzclose(f_);
 	f_ = nullptr;
+	gz_.reset();
 }
 
 bool SeqReader::refill()
 {
 	beg_ = 0;
-	end_ = gzread(f_, buf_.data(), kBuf);
+	end_ = source_read(buf_.data(), kBuf);
 	if (end_ == 0) { eof_ = true; return false; }
 	if (end_ < 0) { eof_ = true; return false; }         /* end_ stays negative: sticky error */
 	return true;
@@ -123,7 +135,7 @@ bool SeqReader::fast_record(int64_t *len)
 		const int keep = end_ - beg_;
 		if (keep > kBuf / 2) return false;
 		memmove(buf_.data(), buf_.data() + beg_, (size_t) keep);
-		const int got = gzread(f_, buf_.data() + keep, (unsigned) (kBuf - keep));
+		const int got = source_read(buf_.data() + keep, (unsigned) (kBuf - keep));
 		beg_ = 0;
 		if (got < 0) { end_ = keep; return false; }              /* the general path will hit the error again */
 		if (got == 0) eof_ = true;

@@ -2,7 +2,9 @@
  * seq_reader.hpp -- streaming FASTA/FASTQ record reader over zlib (plain or gzip input).
  *
  * Host-side replacement for the reference's kseq parser as ntsmCount uses it
- * (vendor/kseq.h:177-219 instantiated over gzread at src/FingerPrint.hpp:27).  Record boundaries
+ * (vendor/kseq.h:177-219 instantiated over gzread at src/FingerPrint.hpp:27).  Plain input goes through zlib's
+ * transparent mode like the reference; gzip input is inflated by a decoder thread (gz_stream.hpp, inflate.hpp)
+ * unless NTSM_ZLIB_ONLY is set, which forces gzread for everything.  Record boundaries
  * and sequence bytes must match it exactly because every byte of seq.s reaches the k-mer window
  * (invalid bytes reset it and still count in "Total Bases Considered").  Behaviours kept:
  *   - the first header is searched for anywhere ('>' or '@'), later ones only at a line start;
@@ -20,6 +22,8 @@
 #include <string>
 #include <vector>
 #include <zlib.h>
+
+#include "gz_stream.hpp"
 
 namespace ntsm {
 
@@ -52,7 +56,9 @@ private:
 	int64_t until(bool line, std::vector<char> &dst, int *delim);
 	bool refill();                                       /* false at EOF/error */
 
-	gzFile f_ = nullptr;
+	int source_read(void *dst, unsigned len);            /* gzread semantics: > 0 bytes, 0 end, -1 error */
+	gzFile f_ = nullptr;                                 /* plain files (zlib passes them through) */
+	std::unique_ptr<GzStream> gz_;                       /* gzip files: decoder thread (gz_stream.hpp) */
 	std::vector<unsigned char> buf_;
 	int beg_ = 0, end_ = 0;
 	bool eof_ = false;

@@ -176,8 +176,8 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
     import subprocess
     exe = str(tmp_path / "host_sanitize")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
-    srcs = [os.path.join(ROOT, "tools", "host_sanitize.cpp")] + [os.path.join(host, f) for f in ("seq_reader.cpp", "site_set.cpp", "report.cpp")]
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe] + srcs + ["-lz"], check=True)
+    srcs = [os.path.join(ROOT, "tools", "host_sanitize.cpp")] + [os.path.join(host, f) for f in ("seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "gz_stream.cpp", "crc32_fast.cpp")]
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     reads = [p for p in INPUTS if not os.path.basename(p).startswith("sites")]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
     for sites, k, dupes in (("sites200.fa", 19, 0), ("sites_dupes.fa", 19, 1), ("sites_dupes.fa", 19, 0), ("sites_odd.fa", 19, 0),
@@ -270,7 +270,7 @@ def test_block_parallel_ingest_under_tsan(nt, tmp_path):
     exe = str(tmp_path / "parallel_tsan")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
     srcs = [os.path.join(ROOT, "tools", "parallel_tsan.cpp")] + [os.path.join(host, f) for f in
-            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp")]
+            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "gz_stream.cpp", "crc32_fast.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
     fq = str(tmp_path / "t.fq")
@@ -287,3 +287,146 @@ def test_block_parallel_ingest_under_tsan(nt, tmp_path):
             assert p.returncode == 0, p.stderr.decode()[-3000:]
             outs.add(p.stdout.split(b" parallel=")[0] + b" " + p.stdout.split(b" ")[-1])
         assert len(outs) == 1, outs
+
+
+def _gz_member(data, level=6, strategy=0, wbits=15, memlevel=8):
+    import zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, 16 + wbits, memlevel, strategy)
+    return co.compress(data) + co.flush()
+
+
+def test_gzip_decoder_matches_zlib(nt, tmp_path):
+    """ntsm::Inflate / GzStream (the gzip ingest path) against zlib on streams of every block type (stored, fixed,
+    dynamic), compression level, strategy and window size; sync/full flush blocks, concatenated members, all header
+    fields, trailing garbage; and the failure behaviour gzread has: truncation -> the decodable bytes then a clean
+    end, corrupt data / CRC / length -> -1."""
+    import gzip
+    import io
+    import random
+    import zlib
+    from ntsm_amd.capi import gunzip
+    rng = random.Random(1)
+    p = str(tmp_path / "t.gz")
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(150)),
+                                          bytes(rng.choice(b"FFFF:,#") for _ in range(150))) for i in range(6000))
+    payloads = [b"", b"A", b"ACGT" * 50000, bytes(rng.getrandbits(8) for _ in range(100000)), fq,
+                bytes(rng.choice(b"ab") for _ in range(150000)), b"\x00" * 2500000, bytes((i * 7 + (i >> 8)) & 0xFF for i in range(1 << 19))]
+    n = 0
+    for pi, data in enumerate(payloads):
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                for wbits, memlevel in ((15, 8), (9, 1), (12, 9)):
+                    if (wbits, memlevel) != (15, 8) and not (pi in (4, 5) and level == 6):
+                        continue
+                    open(p, "wb").write(_gz_member(data, level, strategy, wbits, memlevel))
+                    for chunk in ((1 << 16, 7) if len(data) < 20000 else (1 << 16,)):
+                        got, rc = gunzip(p, 0, chunk)
+                        assert rc == 0 and got == data, (pi, level, strategy, wbits, memlevel, chunk, rc, len(got))
+                        n += 1
+    assert n > 150
+    data = b"".join(b"@r%d\nACGTTGCA%d\n+\nFFFFFFFF\n" % (i, i) for i in range(30000))
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts = []
+    for i in range(0, len(data), 70000):
+        parts += [co.compress(data[i:i + 70000]), co.flush(zlib.Z_SYNC_FLUSH if (i // 70000) % 2 else zlib.Z_FULL_FLUSH)]
+    open(p, "wb").write(b"".join(parts) + co.flush())
+    assert gunzip(p) == (data, 0)
+    multi = _gz_member(data[:100000]) + _gz_member(b"") + _gz_member(data[100000:], 1) + _gz_member(data[:10], 0)
+    open(p, "wb").write(multi)
+    assert gunzip(p) == (data + data[:10], 0)
+    open(p, "wb").write(multi + b"garbage after the last member")
+    assert gunzip(p) == gunzip(p, 1) == (data + data[:10], 0)
+    bio = io.BytesIO()
+    with gzip.GzipFile(filename="some name.fq", mode="wb", fileobj=bio, mtime=12345) as f:
+        f.write(data)
+    open(p, "wb").write(bio.getvalue())
+    assert gunzip(p) == (data, 0)
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = raw.compress(data) + raw.flush()
+    hdr = bytes([0x1f, 0x8b, 8, 2 | 4 | 8 | 16, 1, 2, 3, 4, 0, 3]) + (5).to_bytes(2, "little") + b"EXTRA" + b"name\0" + b"comment\0"
+    hdr += (zlib.crc32(hdr) & 0xFFFF).to_bytes(2, "little")
+    open(p, "wb").write(hdr + body + zlib.crc32(data).to_bytes(4, "little") + (len(data) & 0xFFFFFFFF).to_bytes(4, "little"))
+    assert gunzip(p) == gunzip(p, 1) == (data, 0)
+    good = _gz_member(data)
+    for blob in (good[:-8] + bytes([good[-8] ^ 1]) + good[-7:], good[:-4] + bytes([good[-4] ^ 1]) + good[-3:]):   # CRC, ISIZE
+        open(p, "wb").write(blob)
+        got, rc = gunzip(p)
+        assert rc == -1 and gunzip(p, 1)[1] == -1 and got == data
+    for cut in [len(good) - k for k in (1, 4, 7, 8, 9, 20)] + [rng.randrange(11, len(good)) for _ in range(40)] + [10, 11, 12, 3, 9]:
+        open(p, "wb").write(good[:cut])
+        got, rc = gunzip(p)
+        ref, rrc = gunzip(p, 1)
+        assert rc == rrc == 0 and got == ref, ("truncated at", cut, rc, rrc, len(got), len(ref))
+    for _ in range(120):                                            # single bit flips: same verdict as zlib
+        b = bytearray(good)
+        i = rng.randrange(10, len(good) - 8)
+        b[i] ^= 1 << rng.randrange(8)
+        open(p, "wb").write(bytes(b))
+        got, rc = gunzip(p)
+        ref, rrc = gunzip(p, 1)
+        assert rc == rrc and (rc != 0 or got == ref), ("flip", i, rc, rrc)
+    for hdr_bad in (b"\x1f\x8b\x07" + good[3:], good[:3] + b"\x20" + good[4:]):     # method != 8, reserved flag
+        open(p, "wb").write(hdr_bad)
+        assert gunzip(p)[1] == -1 and gunzip(p, 1)[1] == -1
+
+
+def test_gzip_reader_paths_agree(nt, tmp_path, monkeypatch):
+    """SeqReader over the decoder thread == SeqReader over zlib (NTSM_ZLIB_ONLY) on every gzip input of the
+    golden set and on a multi-member FASTQ."""
+    import glob
+    gz_inputs = sorted(glob.glob(os.path.join(G, "inputs", "*.gz")))
+    assert gz_inputs
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=9, p_embed=0.2)
+    fq = str(tmp_path / "m.fq")
+    s.write_fastq(fq, 0, 20000)
+    raw = open(fq, "rb").read()
+    multi = str(tmp_path / "multi.fq.gz")
+    open(multi, "wb").write(_gz_member(raw[:1_000_003], 1) + _gz_member(raw[1_000_003:4_000_000], 9) + _gz_member(raw[4_000_000:], 6))
+    for path in gz_inputs + [multi]:
+        monkeypatch.delenv("NTSM_ZLIB_ONLY", raising=False)
+        a = nt.flatten_file(path)
+        monkeypatch.setenv("NTSM_ZLIB_ONLY", "1")
+        b = nt.flatten_file(path)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], path
+    monkeypatch.delenv("NTSM_ZLIB_ONLY", raising=False)
+    plain = nt.flatten_file(fq)
+    got = nt.flatten_file(multi)
+    assert np.array_equal(plain[0], got[0]) and np.array_equal(plain[1], got[1])
+
+
+def test_gzip_decoder_corrupt_streams_under_asan(nt, tmp_path):
+    """Memory safety of the decoder on hostile input: byte-level mutations, spliced and truncated streams, run under
+    AddressSanitizer + UBSan (the decoder must fail or finish, never read or write out of bounds)."""
+    import random
+    import subprocess
+    import zlib
+    exe = str(tmp_path / "gunzip_sanitize")
+    host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
+    srcs = [os.path.join(ROOT, "tools", "gunzip_sanitize.cpp")] + [os.path.join(host, f) for f in ("gz_stream.cpp", "inflate.cpp", "crc32_fast.cpp")]
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
+    rng = random.Random(7)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(100)), b"F" * 100) for i in range(3000))
+    seeds = [_gz_member(text, 6), _gz_member(text, 1, zlib.Z_FIXED), _gz_member(text, 9, zlib.Z_DEFAULT_STRATEGY, 9, 1),
+             _gz_member(bytes(rng.getrandbits(8) for _ in range(70000)), 0), _gz_member(text[:50000], 6) + _gz_member(text[50000:], 6)]
+    files = []
+    for k in range(400):
+        b = bytearray(rng.choice(seeds))
+        kind = k % 4
+        if kind == 0:                                               # a few random bytes replaced (often inside the code tables)
+            for _ in range(rng.randrange(1, 6)):
+                b[rng.randrange(10, len(b))] = rng.getrandbits(8)
+        elif kind == 1:                                             # truncated, random tail appended
+            b = b[:rng.randrange(10, len(b))] + bytes(rng.getrandbits(8) for _ in range(rng.randrange(0, 300)))
+        elif kind == 2:                                             # spliced: head of one stream, middle of another
+            o = rng.choice(seeds)
+            b = b[:rng.randrange(10, len(b))] + o[rng.randrange(10, len(o)):]
+        else:                                                       # header followed by noise
+            b = b[:10] + bytes(rng.getrandbits(8) for _ in range(rng.randrange(1, 5000)))
+        path = str(tmp_path / ("c%03d.gz" % k))
+        open(path, "wb").write(bytes(b))
+        files.append(path)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
+    for i in range(0, len(files), 100):
+        p = subprocess.run([exe] + files[i:i + 100], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        assert len(p.stdout.split(b"\n")) == 101

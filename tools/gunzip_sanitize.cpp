@@ -1,0 +1,20 @@
+/* Runs the gzip decoder thread over every file given (tests/test_host_cpu.py builds this with ASan + UBSan and feeds
+ * it corrupted streams): prints "<bytes> <status>" per file. */
+#include <cstdio>
+#include <vector>
+
+#include "../ntsm_amd/csrc/host/gz_stream.hpp"
+
+int main(int argc, char **argv)
+{
+	std::vector<unsigned char> buf(1 << 16);
+	for (int i = 1; i < argc; ++i) {
+		ntsm::GzStream gz;
+		if (!gz.open(argv[i])) { printf("open-failed\n"); continue; }
+		unsigned long long total = 0;
+		int r;
+		while ((r = gz.read(buf.data(), (unsigned) buf.size())) > 0) total += (unsigned long long) r;
+		printf("%llu %d\n", total, r);
+	}
+	return 0;
+}
