@@ -555,6 +555,42 @@ def test_producer_lanes_share_one_context(nt, tmp_path):
     armed.close()
 
 
+def test_staging_pool_and_stream_reuse(nt, tmp_path):
+    """ntsm_staging_pool / ntsm_warmup: slots come out of the pool while it lasts and fall back to individual pinned
+    allocations afterwards, the pool cannot be released while slots are out, and counting through pooled and
+    unpooled lanes gives the oracle's numbers."""
+    s = nt.SynthShort(sites_seed=5, n_sites=2000, read_seed=2, p_embed=0.2, sites_path=str(tmp_path / "s.fa"))
+    sites = nt.Sites(str(tmp_path / "s.fa"))
+    n, per = 60_000, 5_000
+    flat = s.host_bytes(0, n)
+    fp = OracleFP(str(tmp_path / "s.fa"))
+    fp.process_flat(flat, s.read_end(n))
+    nt.warmup(0, 4)                                             # four ready-made streams
+    nt.staging_pool(3 << 20)                                    # room for one 1 MiB lane (2 slots) and a bit
+    nt.staging_pool(1 << 20)                                    # already large enough: fine
+    with pytest.raises(nt.NtsmError):
+        nt.staging_pool(64 << 20)                               # cannot grow
+    ctx = nt.Context(sites.keys)
+    lanes = [ctx.open_lane(1 << 20) for _ in range(3)]          # the 2nd and 3rd exceed the pool
+    with pytest.raises(nt.NtsmError):
+        nt.staging_pool(0)                                      # slots still out
+    ends = s.read_end(per)
+    for b in range(n // per):
+        lanes[b % 3].submit(flat[b * per * s.stride:(b + 1) * per * s.stride], ends)
+    for ln in lanes:
+        ln.close()
+    t = ctx.sync()
+    assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (fp.total_kmers, fp.total_hits, fp.total_bases, n)
+    assert np.array_equal(ctx.counts(), fp.kmers()[2])
+    ctx.close()
+    nt.staging_pool(0)                                          # everything returned: release works
+    nt.staging_pool(0)                                          # idempotent
+    ctx = nt.Context(sites.keys)                                # and the library works without a pool
+    ctx.submit(flat[:per * s.stride], ends)
+    assert ctx.sync().reads_consumed == per
+    ctx.close()
+
+
 def test_cli_block_parallel_single_file(nt, tmp_path):
     """-t N on ONE plain FASTQ: the file is cut into blocks parsed by all N threads (parallel_fastq.hpp); counts and
     summary must be the single-thread bytes, also mixed with files that take the per-file path."""
