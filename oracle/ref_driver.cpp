@@ -18,6 +18,7 @@
  * Flags accepted here are the subset of the reference CLI that reaches the hot path:
  *   -s FILE  -k INT  -m FLOAT  -t INT  -d  -o FILE  -v      (same meaning as
  *   src/ntSeqMatchCount.cpp:75-136).  Output goes to stdout/stderr exactly like the reference.
+ * With NTSM_REF_TIME_SCAN set, the wall time of computeCounts() alone is also printed ("SCAN_SECONDS x").
  */
 #include <cassert>
 #include <cstdlib>
@@ -53,7 +54,10 @@ int main(int argc, char **argv)
 	}
 	double time = omp_get_wtime();
 	FingerPrint fp;                                             /* :177 */
+	const double scan0 = omp_get_wtime();
 	fp.computeCounts(files);                                    /* :178 */
+	if (getenv("NTSM_REF_TIME_SCAN"))                           /* bench.py cpu_baseline: the scan alone, site-table build excluded */
+		std::cerr << "SCAN_SECONDS " << omp_get_wtime() - scan0 << std::endl;
 	fp.printOptionalHeader();                                   /* :179 */
 	fp.printCountsMax();                                        /* :180 */
 	std::cerr << fp.printInfoSummary() << std::endl;            /* :181 */

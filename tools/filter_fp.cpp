@@ -36,6 +36,8 @@ int main(int argc, char **argv)
 	const uint64_t n_blocks = 3ull << e;
 	std::vector<Scheme> schemes = {
 		{ "A: 4 words x 1 bit (current)", 0, 0, 0 },
+		{ "A-ideal: 4 words x 1 bit, four independent 64-bit-mixed hashes", 5, 0, 0 },
+		{ "A-um0: 4 words x 1 bit, bit 0 from um byte 0 instead of raw u byte 3", 6, 0, 0 },
 		{ "B: 1 word, rotr(0x00010001,s1)|rotr(0x00000021,s2)", 1, 0x00010001u, 0x00000021u },
 		{ "B: 1 word, rotr(0x00000101,s1)|rotr(0x00002001,s2)", 1, 0x00000101u, 0x00002001u },
 		{ "B: 1 word, rotr(0x00010001,s1)|rotr(0x00000801,s2) (3-4 bits)", 1, 0x00010001u, 0x00000801u },
@@ -53,7 +55,15 @@ int main(int argc, char **argv)
 		auto bits = [&](uint64_t x, uint32_t *w, uint32_t m[4]) {
 			const uint64_t rc = revcomp(x, 19);
 			const uint32_t u = ntsm_kmer_sum((uint32_t) (x >> 6), (uint32_t) (rc >> 6));
-			if (sc.kind == 0) {
+			if (sc.kind == 5) {
+				uint64_t z = (x ^ (x >> 19)) * 0x9E3779B97F4A7C15ull; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+				m[0] = 1u << (z & 31); m[1] = 1u << ((z >> 8) & 31); m[2] = 1u << ((z >> 16) & 31); m[3] = 1u << ((z >> 24) & 31);
+				*w = 4;
+			} else if (sc.kind == 6) {
+				const uint32_t um = ntsm_kmer_mix(u);
+				m[0] = 1u << (um & 31u); m[1] = 1u << NTSM_KBIT1(um); m[2] = 1u << NTSM_KBIT2(um); m[3] = 1u << NTSM_KBIT3(um);
+				*w = 4;
+			} else if (sc.kind == 0) {
 				const uint32_t um = ntsm_kmer_mix(u);
 				m[0] = 1u << NTSM_KBIT0(u); m[1] = 1u << NTSM_KBIT1(um); m[2] = 1u << NTSM_KBIT2(um); m[3] = 1u << NTSM_KBIT3(um);
 				*w = 4;
