@@ -37,7 +37,8 @@ int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint
 		uint64_t *n_reads, int *last_rc);
 void ntsm_host_free(void *p);
 /* Test hook for the gzip ingest (ntsm_amd/csrc/host/gz_stream.hpp): decode `path` with the decoder thread
- * (engine 0) or with zlib's gzread (engine 1), reading `chunk` bytes per call.  out / len receive the bytes delivered
+ * (engine 0; engine n >= 2: with n decoder threads for BGZF input) or with zlib's gzread (engine 1), reading
+ * `chunk` bytes per call.  out / len receive the bytes delivered
  * (free with ntsm_host_free); returns the last read's result: 0 = clean end, -1 = error, -2 = cannot open. */
 int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out, uint64_t *len);
 /* Block-parallel variant for plain 4-line FASTQ (ntsm_amd/csrc/host/parallel_fastq.hpp), for tests: the records

@@ -10,6 +10,7 @@
 #include <sstream>
 #include <thread>
 
+#include "gz_stream.hpp"
 #include "parallel_fastq.hpp"
 #include <chrono>
 #include "report.hpp"
@@ -242,6 +243,8 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 	 * With -m the reference's parallel schedule is a race; the only defined semantics is
 	 * argv order on one thread, which is what an armed run always uses. */
 	const size_t want = m_maxCounts != 0 ? 1 : std::max(1u, m_opt.threads);
+	/* BGZF (bgzip) input is inflated block-parallel: share the -t threads among the files that are read at once */
+	GzStream::set_decoder_threads((unsigned) std::max<size_t>(1, m_opt.threads / std::max<size_t>(1, std::min(want, filenames.size()))));
 	if (!m_prep.empty()) {
 		const auto tj = std::chrono::steady_clock::now();
 		joinPrep();

@@ -6,7 +6,9 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <cstring>
+#include <map>
 
 #include "crc32_fast.hpp"
 #include "inflate.hpp"
@@ -48,7 +50,29 @@ size_t skip_header(const uint8_t *p, size_t n)
 	}
 	return o;
 }
+/* BGZF member at p: total size of the member (header + data + trailer) from its "BC" extra subfield, 0 if p is not a
+ * complete BGZF member */
+size_t bgzf_member_size(const uint8_t *p, size_t n)
+{
+	if (n < 28 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || p[3] != 4) return 0;       /* FLG = FEXTRA only */
+	const size_t xlen = (size_t) p[10] | ((size_t) p[11] << 8);
+	if (n < 12 + xlen) return 0;
+	for (size_t o = 12; o + 4 <= 12 + xlen;) {
+		const size_t slen = (size_t) p[o + 2] | ((size_t) p[o + 3] << 8);
+		if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) {
+			const size_t bsize = ((size_t) p[o + 4] | ((size_t) p[o + 5] << 8)) + 1;
+			if (bsize < 12 + xlen + 8 || bsize > n) return 0;
+			return bsize;
+		}
+		o += 4 + slen;
+	}
+	return 0;
+}
+
+std::atomic<unsigned> g_decoder_threads { 1 };
 } // namespace
+
+void GzStream::set_decoder_threads(unsigned n) { g_decoder_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
 
 bool GzStream::is_gzip(const std::string &path)
 {
@@ -109,7 +133,7 @@ std::unique_ptr<GzStream::Piece> GzStream::blank()
 		if (!m_free.empty()) {
 			std::unique_ptr<Piece> p = std::move(m_free.front());
 			m_free.pop_front();
-			p->len = 0; p->member_end = false; p->status = 0;
+			p->len = 0; p->member_end = false; p->status = 0; p->checked = false;
 			return p;
 		}
 	}
@@ -141,6 +165,13 @@ void GzStream::produce()
 		push(std::move(e));
 	};
 	bool first = true;
+	const unsigned n_threads = g_decoder_threads;
+	if (n_threads > 1 && bgzf_member_size(p, (size_t) (end - p))) {
+		const uint8_t *q = produce_bgzf(p, n_threads);
+		if (!q) return;
+		if (q != p) first = false;
+		p = q;
+	}
 	for (;;) {
 		/* member header (the first one was recognised by its magic; later ones: anything else is trailing garbage) */
 		if (p == end) { finish(1); return; }
@@ -183,6 +214,117 @@ void GzStream::produce()
 	}
 }
 
+/* Parallel phase over a run of complete BGZF members starting at p. */
+const uint8_t *GzStream::produce_bgzf(const uint8_t *p, unsigned n_threads)
+{
+	constexpr size_t kGroupBytes = 2u << 20;                 /* uncompressed bytes per work item */
+	struct Member { const uint8_t *data, *trailer; uint32_t isize; };
+	struct Group { uint64_t id; std::vector<Member> members; size_t out_bytes; const uint8_t *begin; };
+	struct Done { std::unique_ptr<Piece> piece; bool failed; const uint8_t *resume; };
+	const uint8_t *const end = m_map + m_size;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<Group> work;
+	std::map<uint64_t, Done> done;
+	bool no_more = false, abort = false;
+	auto worker = [&]() {
+		Inflate inf;
+		for (;;) {
+			Group g;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&]() { return abort || no_more || !work.empty(); });
+				if (abort || work.empty()) return;
+				g = std::move(work.front());
+				work.pop_front();
+			}
+			Done d;
+			d.piece = blank();
+			d.failed = false;
+			d.resume = nullptr;
+			if (d.piece->data.size() < g.out_bytes + kSlack) d.piece->data.resize(g.out_bytes + kSlack);
+			d.piece->checked = true;
+			size_t at = 0;
+			const uint8_t *member_begin = g.begin;
+			for (const Member &m : g.members) {
+				inf.reset(m.data, m.trailer);
+				size_t out = 0;
+				Inflate::Status st = Inflate::MORE;
+				while (st == Inflate::MORE && out <= m.isize) st = inf.run(d.piece->data.data() + at, &out, (size_t) m.isize + 1);
+				if (st != Inflate::STREAM_END || out != m.isize || inf.in() != m.trailer ||
+				    crc32_fast(0, d.piece->data.data() + at, out) != le32(m.trailer)) {
+					d.failed = true;                            /* the sequential decoder repeats this member: same bytes, same verdict as zlib */
+					d.resume = member_begin;
+					break;
+				}
+				at += out;
+				member_begin = m.trailer + 8;
+			}
+			d.piece->len = at;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				done.emplace(g.id, std::move(d));
+			}
+			cv.notify_all();
+		}
+	};
+	std::vector<std::thread> pool;
+	for (unsigned i = 0; i < n_threads; ++i) pool.emplace_back(worker);
+	auto shutdown = [&](bool hard) {
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			if (hard) abort = true;
+			no_more = true;
+		}
+		cv.notify_all();
+		for (auto &t : pool) t.join();
+	};
+	uint64_t issued = 0, delivered = 0;
+	const uint8_t *q = p, *resume = nullptr;
+	bool scan_done = false;
+	for (;;) {
+		/* keep the workers fed: up to 3 groups per thread in flight */
+		while (!scan_done && issued - delivered < 3ull * n_threads) {
+			Group g;
+			g.id = issued;
+			g.out_bytes = 0;
+			g.begin = q;
+			while (g.out_bytes < kGroupBytes) {
+				const size_t sz = bgzf_member_size(q, (size_t) (end - q));
+				if (!sz) { scan_done = true; break; }
+				const size_t xlen = (size_t) q[10] | ((size_t) q[11] << 8);
+				Member m { q + 12 + xlen, q + sz - 8, le32(q + sz - 4) };
+				if (m.isize > 65536) { scan_done = true; break; }   /* not BGZF after all */
+				g.members.push_back(m);
+				g.out_bytes += m.isize;
+				q += sz;
+			}
+			if (g.members.empty()) break;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				work.push_back(std::move(g));
+			}
+			cv.notify_all();
+			++issued;
+		}
+		if (delivered == issued) { resume = q; break; }         /* nothing in flight and nothing more to issue */
+		Done d;
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&]() { return done.count(delivered) != 0; });
+			d = std::move(done[delivered]);
+			done.erase(delivered);
+		}
+		++delivered;
+		if (d.piece->len || !d.failed) {
+			if (!push(std::move(d.piece))) { shutdown(true); return nullptr; }
+		}
+		if (d.failed) { resume = d.resume; break; }
+	}
+	shutdown(true);
+	return resume;
+}
+
 int GzStream::read(void *dst, unsigned len)
 {
 	uint8_t *d = (uint8_t *) dst;
@@ -201,8 +343,10 @@ int GzStream::read(void *dst, unsigned len)
 		const size_t n = std::min<size_t>(len - got, m_cur->len - m_off);
 		if (n) {
 			memcpy(d + got, m_cur->data.data() + m_off, n);
-			m_crc = crc32_fast(m_crc, d + got, n);
-			m_len += n;
+			if (!m_cur->checked) {
+				m_crc = crc32_fast(m_crc, d + got, n);
+				m_len += n;
+			}
 			m_off += n;
 			got += (unsigned) n;
 		}

@@ -7,6 +7,13 @@
  * through gzerror() --, -1 on invalid data (bad header, corrupt deflate stream, CRC or length mismatch).
  * Concatenated members are decoded back to back; anything after the last member that does not start with the
  * gzip magic is ignored (zlib gz_look: "trailing garbage").
+ *
+ * Block-parallel inflate: a deflate stream is sequential, but BGZF files (bgzip, samtools, htslib: members of at
+ * most 64 KiB whose header carries their compressed size in a "BC" extra field, SAM spec 4.1) can be cut without
+ * decoding.  With more than one decoder thread the producer walks the member headers, hands groups of members to
+ * worker threads (each member: own Inflate, CRC-32 and length checked by the worker) and passes the finished groups
+ * on in file order; at the first member that is not BGZF, is incomplete or fails, the sequential decoder takes over
+ * at that byte, so every input keeps the single-thread semantics.
  */
 #ifndef NTSM_GZ_STREAM_HPP
 #define NTSM_GZ_STREAM_HPP
@@ -29,6 +36,8 @@ public:
 	GzStream &operator=(const GzStream &) = delete;
 
 	static bool is_gzip(const std::string &path);      /* regular file that starts with 1f 8b */
+	/* decoder threads used for BGZF input by streams opened from now on (process-wide; default 1 = sequential) */
+	static void set_decoder_threads(unsigned n);
 	bool open(const std::string &path);
 	int read(void *dst, unsigned len);
 	void close();
@@ -38,10 +47,12 @@ private:
 		std::vector<uint8_t> data;
 		size_t len = 0;
 		bool member_end = false;                       /* after these bytes a member ends: check crc / isize */
+		bool checked = false;                          /* BGZF group: the workers verified crc / isize already */
 		uint32_t crc = 0, isize = 0;
 		int status = 0;                                /* after these bytes: 0 = more, 1 = end of data, -1 = error */
 	};
 	void produce();
+	const uint8_t *produce_bgzf(const uint8_t *p, unsigned n_threads);   /* returns where the sequential decoder continues, nullptr: reader gone */
 	bool push(std::unique_ptr<Piece> p);               /* false: reader went away */
 	std::unique_ptr<Piece> blank();
 

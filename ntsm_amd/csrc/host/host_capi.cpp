@@ -81,10 +81,12 @@ int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out
 {
 	std::vector<uint8_t> all, buf(chunk ? chunk : 1);
 	int r;
-	if (engine == 0) {
+	if (engine != 1) {
+		ntsm::GzStream::set_decoder_threads(engine >= 2 ? (unsigned) engine : 1u);
 		ntsm::GzStream gz;
 		if (!gz.open(path)) return -2;
 		while ((r = gz.read(buf.data(), (unsigned) buf.size())) > 0) all.insert(all.end(), buf.begin(), buf.begin() + r);
+		ntsm::GzStream::set_decoder_threads(1);
 	} else {
 		gzFile f = gzopen(path, "r");
 		if (!f) return -2;

@@ -394,6 +394,30 @@ def test_gzip_reader_paths_agree(nt, tmp_path, monkeypatch):
     assert np.array_equal(plain[0], got[0]) and np.array_equal(plain[1], got[1])
 
 
+def test_bgzf_parallel_inflate_under_tsan(nt, tmp_path):
+    """Dispatcher / worker / reader threads of the BGZF path under ThreadSanitizer (good file, truncated, corrupt)."""
+    import random
+    import subprocess
+    exe = str(tmp_path / "gunzip_tsan")
+    host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
+    srcs = [os.path.join(ROOT, "tools", "gunzip_sanitize.cpp")] + [os.path.join(host, f) for f in ("gz_stream.cpp", "inflate.cpp", "crc32_fast.cpp")]
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
+    rng = random.Random(5)
+    data = bytes(rng.choice(b"ACGTN\n@+F") for _ in range(3_000_000))
+    good = _bgzf(data, level=1)
+    bad = bytearray(good)
+    bad[len(good) // 2] ^= 0x10
+    files = []
+    for name, blob in (("good", good), ("trunc", good[:len(good) * 2 // 3]), ("bad", bytes(bad))):
+        path = str(tmp_path / (name + ".gz"))
+        open(path, "wb").write(blob)
+        files.append(path)
+    p = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", NTSM_DECODER_THREADS="6"))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = p.stdout.split()
+    assert out[0:2] == [b"%d" % len(data), b"0"] and out[3] == b"0" and out[5] == b"-1", out
+
+
 def test_gzip_decoder_corrupt_streams_under_asan(nt, tmp_path):
     """Memory safety of the decoder on hostile input: byte-level mutations, spliced and truncated streams, run under
     AddressSanitizer + UBSan (the decoder must fail or finish, never read or write out of bounds)."""
@@ -430,3 +454,58 @@ def test_gzip_decoder_corrupt_streams_under_asan(nt, tmp_path):
         p = subprocess.run([exe] + files[i:i + 100], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert p.returncode == 0, p.stderr.decode()[-3000:]
         assert len(p.stdout.split(b"\n")) == 101
+
+
+def _bgzf(data, level=6, eof=True, blk=65280):
+    """BGZF (bgzip) container: independent gzip members of <= 64 KiB with a BC extra field (SAM spec 4.1)."""
+    import struct
+    import zlib
+
+    def block(d):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(d) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        return (b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + body +
+                struct.pack("<II", zlib.crc32(d), len(d)))
+    return b"".join(block(data[i:i + blk]) for i in range(0, len(data), blk)) + (block(b"") if eof else b"")
+
+
+def test_bgzf_block_parallel_inflate(nt, tmp_path):
+    """BGZF input decoded by several decoder threads == zlib's gzread on the same file: whole files, no EOF marker,
+    tiny blocks, plain gzip members before/after, trailing garbage, truncation, a corrupt block, a wrong BSIZE."""
+    import random
+    from ntsm_amd.capi import gunzip
+    rng = random.Random(3)
+    data = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(150)),
+                                            bytes(rng.choice(b"FFFF:,#") for _ in range(150))) for i in range(20000))
+    p = str(tmp_path / "t.bgzf.gz")
+    open(p, "wb").write(_bgzf(data))
+    for eng in (0, 1, 2, 5, 16):
+        assert gunzip(p, eng, 1 << 20) == (data, 0), eng
+    good = _bgzf(data)
+    cut = len(data) // 3
+    cases = {"noeof": _bgzf(data, eof=False), "small": _bgzf(data[:200000], blk=1000), "plain_after": _bgzf(data[:cut]) + _gz_member(data[cut:]),
+             "plain_before": _gz_member(data[:cut]) + _bgzf(data[cut:]), "garbage": good + b"trailing garbage", "empty": _bgzf(b""),
+             "trunc1": good[:len(good) // 2], "trunc2": good[:len(good) - 30], "trunc3": good[:777]}
+    bad = bytearray(good)
+    bad[len(good) // 3] ^= 0x40
+    cases["flip"] = bytes(bad)
+    bad = bytearray(good)
+    bad[16] ^= 1
+    cases["bsize"] = bytes(bad)
+    for name, blob in cases.items():
+        open(p, "wb").write(blob)
+        ref = gunzip(p, 1)
+        for eng in (0, 3, 8):
+            got = gunzip(p, eng, 1 << 16)
+            assert got[1] == ref[1] and (got[0] == ref[0] or ref[1] == -1), (name, eng, got[1], ref[1], len(got[0]), len(ref[0]))
+    assert gunzip(p, 8)[1] == 0                                     # "bsize": falls back to the sequential decoder, still fine
+    # through the reader: parallel BGZF == plain text
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=4, p_embed=0.2)
+    fq = str(tmp_path / "b.fq")
+    s.write_fastq(fq, 0, 15000)
+    open(p, "wb").write(_bgzf(open(fq, "rb").read(), level=1))
+    plain = nt.flatten_file(fq)
+    nt.capi.HO.ntsm_host_gunzip                                    # (decoder thread count is process-wide: set through the hook)
+    got = nt.flatten_file(p)
+    assert np.array_equal(plain[0], got[0]) and np.array_equal(plain[1], got[1])

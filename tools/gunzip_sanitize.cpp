@@ -1,6 +1,7 @@
 /* Runs the gzip decoder thread over every file given (tests/test_host_cpu.py builds this with ASan + UBSan and feeds
  * it corrupted streams): prints "<bytes> <status>" per file. */
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../ntsm_amd/csrc/host/gz_stream.hpp"
@@ -8,6 +9,7 @@
 int main(int argc, char **argv)
 {
 	std::vector<unsigned char> buf(1 << 16);
+	if (const char *t = getenv("NTSM_DECODER_THREADS")) ntsm::GzStream::set_decoder_threads((unsigned) atoi(t));   /* BGZF: block-parallel */
 	for (int i = 1; i < argc; ++i) {
 		ntsm::GzStream gz;
 		if (!gz.open(argv[i])) { printf("open-failed\n"); continue; }
