@@ -39,14 +39,20 @@ void Feeder::die(int rc, const char *what) const
 }
 
 static std::mutex g_stderr;
-static constexpr uint64_t kLaneBytes = 16ull << 20;     /* staging slot of a producer lane (-t N) */
+/* Staging slot of a producer lane (-t N): 16 MiB, less when many threads would pin more than 1 GiB in total */
+static uint64_t lane_bytes(unsigned threads)
+{
+	uint64_t b = 16ull << 20;
+	while (b > (2ull << 20) && 2ull * threads * b > (1ull << 30)) b >>= 1;
+	return b;
+}
 
 Feeder::Feeder(const Options &opt, ntsm_ctx *ctx, uint64_t max_hits, bool lane) : m_opt(opt), m_ctx(ctx), m_useLane(lane), m_maxCounts(max_hits)
 {
 	m_cfgBytes = m_opt.batch_bytes < 4096 ? 4096 : m_opt.batch_bytes;
 	if (m_useLane) {
 		/* N producers share the GPU: smaller slots keep the pinned footprint (and its allocation time) flat */
-		m_cfgBytes = std::max<uint64_t>(4096, std::min<uint64_t>(m_cfgBytes, kLaneBytes));
+		m_cfgBytes = std::max<uint64_t>(4096, std::min<uint64_t>(m_cfgBytes, lane_bytes(m_opt.threads)));
 		openLane();
 	} else {
 		int rc = ntsm_set_batch_capacity(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16);
@@ -153,7 +159,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 		const bool maybe_armed = m_opt.covThresh != 0 && m_opt.covThresh < 1e300;
 		const bool lanes = m_opt.threads > 1 && !maybe_armed;
 		const uint64_t slot = std::max<uint64_t>(4096, m_opt.batch_bytes);
-		const uint64_t pool_bytes = lanes ? (uint64_t) m_opt.threads * 2 * (std::min<uint64_t>(slot, kLaneBytes) + 8192)
+		const uint64_t pool_bytes = lanes ? (uint64_t) m_opt.threads * 2 * (std::min<uint64_t>(slot, lane_bytes(m_opt.threads)) + 8192)
 		                                  : 2 * (slot + 8192 + (slot / 64 + 16) * 8 + 8192);
 		const int lanes_per_dev = lanes ? (int) ((m_opt.threads + m_ctxDevice.size() - 1) / m_ctxDevice.size()) : 0;
 		for (size_t i = 0; i < m_ctxDevice.size(); ++i) {
@@ -264,7 +270,8 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 	std::vector<std::string> rest;
 	for (const std::string &fn : filenames) {
 		ParallelFastq pf;
-		if (!pf.open(fn, m_opt.block_bytes)) { rest.push_back(fn); continue; }
+		/* a block's sequences (< half its bytes) must fit one lane slot: no waiting for the predecessor mid-block */
+		if (!pf.open(fn, std::min<uint64_t>(m_opt.block_bytes, lane_bytes(m_opt.threads)))) { rest.push_back(fn); continue; }
 		const auto tp0 = std::chrono::steady_clock::now();
 		if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "block-parallel: " << pf.n_blocks() << " blocks, " << want << " threads" << std::endl;
 		std::vector<Feeder *> sinks;
