@@ -200,7 +200,7 @@ bool Inflate::read_dynamic_header()
 }
 
 /* Symbols of one Huffman block.  Returns MORE (output limit), STREAM_END (here: end of BLOCK), TRUNCATED, DATA_ERROR. */
-Inflate::Status Inflate::run_huffman(uint8_t *buf, size_t *out, size_t out_stop)
+NTSM_INFLATE_CLONES Inflate::Status Inflate::run_huffman(uint8_t *buf, size_t *out, size_t out_stop)
 {
 	const uint8_t *in = m_in;
 	uint64_t bb = m_bb;
