@@ -225,23 +225,8 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 #ifndef NTSM_FAST_WAVES
 #define NTSM_FAST_WAVES 4                              /* waves per SIMD the register budget is held to */
 #endif
-#ifndef NTSM_FAST_BRANCHLESS_PUSH
-#define NTSM_FAST_BRANCHLESS_PUSH 0
-#endif
-#ifndef NTSM_FAST_ASM_LSHLOR
-#define NTSM_FAST_ASM_LSHLOR 1                        /* one v_lshl_or_b32 for the forward word (hipcc emits shift + or): +1 % */
-#endif
-#if NTSM_FAST_ASM_LSHLOR
+/* forward word update in one v_lshl_or_b32 (hipcc emits shift + or for the C expression: +1 %) */
 #define NTSM_F_UPDATE(c_) asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(F) : "v"(F), "v"(c_));
-#else
-#define NTSM_F_UPDATE(c_) F = (F << 2) | (c_);
-#endif
-#ifndef NTSM_FAST_EARLY_LOADS
-#define NTSM_FAST_EARLY_LOADS 1                        /* issue each filter load right after its offset is known (+2 %) */
-#endif
-#ifndef NTSM_FAST_LDS_PREFETCH
-#define NTSM_FAST_LDS_PREFETCH 0                       /* base-table reads of block b+1 issued before phase C of block b (+1 %, 16 VGPRs: spent on the 128-bit filter blocks instead) */
-#endif
 constexpr int kFastC = 128;
 constexpr int kQueueCap = 128;                         /* < 64 left over + one position's burst of <= 64 */
 
@@ -430,24 +415,16 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 				mz_prev = mz;
 				ok_prev = B.ok[j];
 				nk += B.ok[j] ? 1u : 0u;
-#if NTSM_FAST_EARLY_LOADS
-				{   /* issue each block load as soon as its offset is known: earlier positions get the rest of the block as cover */
+				{   /* issue each block load as soon as its offset is known: earlier positions get the rest of the block as
+				     * cover (+2 % over issuing the eight loads together at the end of the phase) */
 					const u32x4v bv = __builtin_amdgcn_raw_buffer_load_b128(blk_rsrc, (int) idx[j], 0, 0);
 					B.bl[j] = make_uint4(bv.x, bv.y, bv.z, bv.w);
 				}
-#endif
 			}
 			fc0 = fh[5]; fc1 = fh[6]; fc2 = fh[7];
 			sprev[7] = gg[7];
 #pragma unroll
 			for (int j = 6; j >= 9 - NTSM_FAST_W; --j) sprev[j] = min(gg[j], sprev[j + 1]);
-#if !NTSM_FAST_EARLY_LOADS
-#pragma unroll
-			for (int j = 0; j < 8; ++j) {                      /* buffer loads: 32-bit byte offset, range-checked by the descriptor */
-				const u32x4v bv = __builtin_amdgcn_raw_buffer_load_b128(blk_rsrc, (int) idx[j], 0, 0);
-				B.bl[j] = make_uint4(bv.x, bv.y, bv.z, bv.w);
-			}
-#endif
 		};
 		/* Phase C: two-bit test against the (possibly just fetched) block; positives go to the queue */
 		auto phase_c = [&](const BlockState &B, const int pos0) {
@@ -475,23 +452,10 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 
 		BlockState S;
 		uint2 e8[8];
-		/* LDS prefetch (not in the -m variant, which has no registers to spare): the tile word of block b+2 and
-		 * the base-table entries of block b+1 are requested while block b is still being tested, so a block never
-		 * starts by waiting for two LDS round trips */
-		constexpr bool kPrefetch = NTSM_FAST_LDS_PREFETCH && !PER_READ;
-		uint2 wn = make_uint2(0, 0);
-		if (kPrefetch) {
-			lut_reads(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, 0)), e8);
-			wn = *reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, 8));
-		}
 #pragma unroll 1
 		for (int b = 0; b < NB; ++b) {
-			if (!kPrefetch) lut_reads(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, b * 8)), e8);
+			lut_reads(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, b * 8)), e8);
 			phase_a(e8, S);
-			if (kPrefetch) {
-				if (b + 1 < NB) lut_reads(wn, e8);
-				if (b + 2 < NB) wn = *reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, (b + 2) * 8));
-			}
 			phase_c(S, t * C + b * 8);
 		}
 		drain(true);
