@@ -28,6 +28,7 @@
 #include <cstring>
 #include <new>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/ntsm_hip.h"
@@ -683,127 +684,145 @@ namespace {
 int build_tables(ntsm_ctx *c, int filter_log2_req)
 {
 	const uint32_t n = c->n_kmers;
-	/* slots: power of two with load <= 0.4; at least 32 */
-	uint64_t slots = 32;
-	while ((double) n > 0.4 * (double) slots) slots <<= 1;
+	/* The four structures are independent functions of the key set: built on four host threads (the cuckoo table
+	 * dominates), uploaded afterwards. */
 	std::vector<uint64_t> keys;
-	for (;; slots <<= 1) {
-		const uint32_t blog = (uint32_t) __builtin_ctzll(slots >> 1);
-		const uint32_t bshift = 32 - blog;
-		keys.assign(slots, NTSM_EMPTY_KEY);
-		c->slot_of.assign(n, 0);
-		std::vector<uint32_t> owner(slots, 0);            /* dense index stored in each slot */
-		bool ok = true;
-		uint64_t rng = 0x9E3779B97F4A7C15ull;
-		for (uint32_t i = 0; i < n && ok; ++i) {
-			uint64_t key = c->canon[i];
-			uint32_t idx = i;
-			/* duplicate check against both candidate buckets */
-			{
-				const uint32_t f = ntsm_fold(key);
-				const uint64_t b[2] = { 2ull * (ntsm_h1(f) >> bshift), 2ull * (ntsm_h2(f) >> bshift) };
-				for (int q = 0; q < 2; ++q)
-					for (int s = 0; s < 2; ++s)
-						if (keys[b[q] + s] == key) return NTSM_ERR_DUP_KEY;
+	std::vector<uint32_t> filter, blocks /* 4 words per block */, prefilter;
+	int cuckoo_rc = NTSM_OK;
+	auto build_cuckoo = [&]() {
+		/* slots: power of two with load <= 0.4; at least 32 */
+		uint64_t slots = 32;
+		while ((double) n > 0.4 * (double) slots) slots <<= 1;
+		for (;; slots <<= 1) {
+			const uint32_t blog = (uint32_t) __builtin_ctzll(slots >> 1);
+			const uint32_t bshift = 32 - blog;
+			keys.assign(slots, NTSM_EMPTY_KEY);
+			c->slot_of.assign(n, 0);
+			std::vector<uint32_t> owner(slots, 0);            /* dense index stored in each slot */
+			bool ok = true;
+			uint64_t rng = 0x9E3779B97F4A7C15ull;
+			for (uint32_t i = 0; i < n && ok; ++i) {
+				uint64_t key = c->canon[i];
+				uint32_t idx = i;
+				/* duplicate check against both candidate buckets */
+				{
+					const uint32_t f = ntsm_fold(key);
+					const uint64_t b[2] = { 2ull * (ntsm_h1(f) >> bshift), 2ull * (ntsm_h2(f) >> bshift) };
+					for (int q = 0; q < 2; ++q)
+						for (int s = 0; s < 2; ++s)
+							if (keys[b[q] + s] == key) { cuckoo_rc = NTSM_ERR_DUP_KEY; return; }
+				}
+				bool placed = false;
+				for (int kick = 0; kick < 1000 && !placed; ++kick) {
+					const uint32_t f = ntsm_fold(key);
+					const uint64_t b[2] = { 2ull * (ntsm_h1(f) >> bshift), 2ull * (ntsm_h2(f) >> bshift) };
+					for (int q = 0; q < 2 && !placed; ++q)
+						for (int s = 0; s < 2 && !placed; ++s)
+							if (keys[b[q] + s] == NTSM_EMPTY_KEY) {
+								keys[b[q] + s] = key;
+								owner[b[q] + s] = idx;
+								placed = true;
+							}
+					if (placed) break;
+					rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+					const uint64_t victim = b[(rng >> 33) & 1] + ((rng >> 34) & 1);
+					std::swap(key, keys[victim]);
+					std::swap(idx, owner[victim]);
+				}
+				if (!placed) ok = false;
 			}
-			bool placed = false;
-			for (int kick = 0; kick < 1000 && !placed; ++kick) {
-				const uint32_t f = ntsm_fold(key);
-				const uint64_t b[2] = { 2ull * (ntsm_h1(f) >> bshift), 2ull * (ntsm_h2(f) >> bshift) };
-				for (int q = 0; q < 2 && !placed; ++q)
-					for (int s = 0; s < 2 && !placed; ++s)
-						if (keys[b[q] + s] == NTSM_EMPTY_KEY) {
-							keys[b[q] + s] = key;
-							owner[b[q] + s] = idx;
-							placed = true;
-						}
-				if (placed) break;
-				rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-				const uint64_t victim = b[(rng >> 33) & 1] + ((rng >> 34) & 1);
-				std::swap(key, keys[victim]);
-				std::swap(idx, owner[victim]);
-			}
-			if (!placed) ok = false;
+			if (!ok) continue;                                /* grow and retry */
+			for (uint64_t s = 0; s < slots; ++s)
+				if (keys[s] != NTSM_EMPTY_KEY) c->slot_of[owner[s]] = (uint32_t) s;
+			c->n_slots = slots;
+			c->bucket_log2 = blog;
+			break;
 		}
-		if (!ok) continue;                                /* grow and retry */
-		for (uint64_t s = 0; s < slots; ++s)
-			if (keys[s] != NTSM_EMPTY_KEY) c->slot_of[owner[s]] = (uint32_t) s;
-		c->n_slots = slots;
-		c->bucket_log2 = blog;
-		break;
-	}
-	/* filter: >= 8 bits per key, 2^16 .. 2^28 bits; F = 24 (2 MiB) for the 1.5 M-key human set */
-	uint32_t flog = 16;
-	while (flog < 28 && (1ull << flog) < 8ull * n) ++flog;
-	if (filter_log2_req >= 10 && filter_log2_req <= 30) flog = (uint32_t) filter_log2_req;
-	c->filter_log2 = flog;
-	std::vector<uint32_t> filter((1ull << flog) / 32, 0);
-	const uint32_t fshift = 32 - flog;
-	for (uint32_t i = 0; i < n; ++i) {
-		const uint32_t bit = ntsm_h1(ntsm_fold(c->canon[i])) >> fshift;
-		filter[bit >> 5] |= 1u << (bit & 31);
-	}
-	/* k = 19: minimizer-addressed blocked filter.  Size = smallest of {2^e, 3 * 2^(e-2)} blocks with at least
-	 * 12 bits per key: 3 MiB for the 1.54 M-key human set -- it must leave room in the 4 MiB per-XCD L2 for the
-	 * read stream and the bucket lines, a full 4 MiB filter misses L2 on 18 % of its reads. */
-	std::vector<uint32_t> blocks;                          /* 4 words per block */
-	if (c->k == NTSM_FAST_K) {
-		uint32_t e = 6, mult = 1;
-		if (filter_log2_req >= 100 && filter_log2_req <= 130) {          /* 100 + v: 3 * 2^v bits */
-			mult = 3; e = (uint32_t) (filter_log2_req - 100) - 7;
-		} else if (filter_log2_req >= 10 && filter_log2_req <= 30) {
-			e = (uint32_t) filter_log2_req - 7;
-		} else {
-			const uint64_t want = (12ull * n + 127) / 128;                /* blocks */
-			while ((1ull << e) < want && e < 21) ++e;
-			if (e > 8 && (3ull << (e - 2)) >= want) { mult = 3; e -= 2; }   /* 0.75 * 2^e is enough */
-		}
-		if (e > 20) e = 20;
-		if (e < 4) e = 4;
-		const uint32_t slack = 24 - e < 6 ? 24 - e : 6;                   /* e + slack <= 24 (mul24 operand), slack >= 4 */
-		c->n_blocks = (uint64_t) mult << e;
-		c->blk_map.qshift = 32 - (e + slack);
-		c->blk_map.mult = mult;
-		c->blk_map.sshift = slack - 4;
-		blocks.assign(c->n_blocks * 4, 0u);
+	};
+	auto build_filter = [&]() {
+		/* filter: >= 8 bits per key, 2^16 .. 2^28 bits; F = 24 (2 MiB) for the 1.5 M-key human set */
+		uint32_t flog = 16;
+		while (flog < 28 && (1ull << flog) < 8ull * n) ++flog;
+		if (filter_log2_req >= 10 && filter_log2_req <= 30) flog = (uint32_t) filter_log2_req;
+		c->filter_log2 = flog;
+		filter.assign((1ull << flog) / 32, 0);
+		const uint32_t fshift = 32 - flog;
 		for (uint32_t i = 0; i < n; ++i) {
-			const uint64_t x = c->canon[i];
-			uint64_t rc = 0;
-			for (int b = 0; b < NTSM_FAST_K; ++b) rc |= (3ull - ((x >> (2 * b)) & 3ull)) << (2 * (NTSM_FAST_K - 1 - b));
-			uint32_t mz = 0xFFFFFFFFu;
-			for (int j = 0; j < NTSM_FAST_W; ++j) {
-				const uint32_t sub = (uint32_t) (x >> (2 * j)) & NTSM_MMER_MASK;
-				uint32_t rsub = 0;
-				for (int b = 0; b < NTSM_FAST_M; ++b) rsub |= (3u - ((sub >> (2 * b)) & 3u)) << (2 * (NTSM_FAST_M - 1 - b));
-				mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
+			const uint32_t bit = ntsm_h1(ntsm_fold(c->canon[i])) >> fshift;
+			filter[bit >> 5] |= 1u << (bit & 31);
+		}
+	};
+	auto build_blocks = [&]() {
+		/* k = 19: minimizer-addressed blocked filter.  Size = smallest of {2^e, 3 * 2^(e-2)} blocks with at least
+		 * 12 bits per key: 3 MiB for the 1.54 M-key human set -- it must leave room in the 4 MiB per-XCD L2 for the
+		 * read stream and the bucket lines, a full 4 MiB filter misses L2 on 18 % of its reads. */
+		if (c->k == NTSM_FAST_K) {
+			uint32_t e = 6, mult = 1;
+			if (filter_log2_req >= 100 && filter_log2_req <= 130) {          /* 100 + v: 3 * 2^v bits */
+				mult = 3; e = (uint32_t) (filter_log2_req - 100) - 7;
+			} else if (filter_log2_req >= 10 && filter_log2_req <= 30) {
+				e = (uint32_t) filter_log2_req - 7;
+			} else {
+				const uint64_t want = (12ull * n + 127) / 128;                /* blocks */
+				while ((1ull << e) < want && e < 21) ++e;
+				if (e > 8 && (3ull << (e - 2)) >= want) { mult = 3; e -= 2; }   /* 0.75 * 2^e is enough */
 			}
-			const uint32_t u = ntsm_kmer_sum((uint32_t) (x >> 6), (uint32_t) (rc >> 6)), um = ntsm_kmer_mix(u);
-			uint32_t *blk = &blocks[(ntsm_block_off(mz, c->blk_map) >> 4) * 4];
-			blk[0] |= 1u << NTSM_KBIT0(u);
-			blk[1] |= 1u << NTSM_KBIT1(um);
-			blk[2] |= 1u << NTSM_KBIT2(um);
-			blk[3] |= 1u << NTSM_KBIT3(um);
+			if (e > 20) e = 20;
+			if (e < 4) e = 4;
+			const uint32_t slack = 24 - e < 6 ? 24 - e : 6;                   /* e + slack <= 24 (mul24 operand), slack >= 4 */
+			c->n_blocks = (uint64_t) mult << e;
+			c->blk_map.qshift = 32 - (e + slack);
+			c->blk_map.mult = mult;
+			c->blk_map.sshift = slack - 4;
+			blocks.assign(c->n_blocks * 4, 0u);
+			for (uint32_t i = 0; i < n; ++i) {
+				const uint64_t x = c->canon[i];
+				/* reverse complement of the 38-bit code: complement, then reverse the 2-bit groups of the 64-bit word */
+				uint64_t rc = ~x;
+				rc = ((rc >> 2) & 0x3333333333333333ull) | ((rc & 0x3333333333333333ull) << 2);
+				rc = ((rc >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((rc & 0x0F0F0F0F0F0F0F0Full) << 4);
+				rc = __builtin_bswap64(rc) >> (64 - 2 * NTSM_FAST_K);
+				uint32_t mz = 0xFFFFFFFFu;
+				for (int j = 0; j < NTSM_FAST_W; ++j) {                 /* the m-mer at offset j and its reverse complement */
+					const uint32_t sub = (uint32_t) (x >> (2 * j)) & NTSM_MMER_MASK;
+					const uint32_t rsub = (uint32_t) (rc >> (2 * (NTSM_FAST_K - NTSM_FAST_M - j))) & NTSM_MMER_MASK;
+					mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
+				}
+				const uint32_t u = ntsm_kmer_sum((uint32_t) (x >> 6), (uint32_t) (rc >> 6)), um = ntsm_kmer_mix(u);
+				uint32_t *blk = &blocks[(ntsm_block_off(mz, c->blk_map) >> 4) * 4];
+				blk[0] |= 1u << NTSM_KBIT0(u);
+				blk[1] |= 1u << NTSM_KBIT1(um);
+				blk[2] |= 1u << NTSM_KBIT2(um);
+				blk[3] |= 1u << NTSM_KBIT3(um);
+			}
+			if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0u);   /* ablation only: wrong counts */
 		}
-		if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0u);   /* ablation only: wrong counts */
-	}
-	/* second-level filter of the fast path: plain Bloom, 2 bits per key in one 32-bit word, >= 5 bits per key
-	 * (1 MiB for the human set: with the 3 MiB first level it still fits the 4 MiB per-XCD L2) */
-	std::vector<uint32_t> prefilter;
-	if (c->k == NTSM_FAST_K) {
-		uint32_t pl = 10;
-		while (pl < 28 && (1ull << pl) < 5ull * n) ++pl;
-		if (const char *ev = getenv("NTSM_PREFILTER_LOG2")) pl = (uint32_t) atoi(ev);
-		if (pl < 10) pl = 10;
-		if (pl > 30) pl = 30;
-		c->prefilter_log2 = pl;
-		prefilter.assign((1ull << pl) / 32, 0u);
-		const uint32_t pshift = 32 - (pl - 5);
-		for (uint32_t i = 0; i < n; ++i) {
-			const uint32_t f = ntsm_fold(c->canon[i]), g1 = ntsm_h1(f), g2 = ntsm_h2(f);
-			prefilter[g1 >> pshift] |= (1u << (g2 & 31u)) | (1u << ((g2 >> 5) & 31u));
+	};
+	auto build_prefilter = [&]() {
+		/* second-level filter of the fast path: plain Bloom, 2 bits per key in one 32-bit word, >= 5 bits per key
+		 * (1 MiB for the human set: with the 3 MiB first level it still fits the 4 MiB per-XCD L2) */
+		if (c->k == NTSM_FAST_K) {
+			uint32_t pl = 10;
+			while (pl < 28 && (1ull << pl) < 5ull * n) ++pl;
+			if (const char *ev = getenv("NTSM_PREFILTER_LOG2")) pl = (uint32_t) atoi(ev);
+			if (pl < 10) pl = 10;
+			if (pl > 30) pl = 30;
+			c->prefilter_log2 = pl;
+			prefilter.assign((1ull << pl) / 32, 0u);
+			const uint32_t pshift = 32 - (pl - 5);
+			for (uint32_t i = 0; i < n; ++i) {
+				const uint32_t f = ntsm_fold(c->canon[i]), g1 = ntsm_h1(f), g2 = ntsm_h2(f);
+				prefilter[g1 >> pshift] |= (1u << (g2 & 31u)) | (1u << ((g2 >> 5) & 31u));
+			}
+			if (getenv("NTSM_PREFILTER_OFF")) std::fill(prefilter.begin(), prefilter.end(), 0xFFFFFFFFu);   /* ablation: everything passes */
 		}
-		if (getenv("NTSM_PREFILTER_OFF")) std::fill(prefilter.begin(), prefilter.end(), 0xFFFFFFFFu);   /* ablation: everything passes */
+	};
+	{
+		std::thread t1(build_filter), t2(build_blocks), t3(build_prefilter);
+		build_cuckoo();
+		t1.join(); t2.join(); t3.join();
 	}
+	if (cuckoo_rc) return cuckoo_rc;
 	/* upload */
 	if (c->d_blocks) (void) hipFree(c->d_blocks);
 	if (c->d_prefilter) (void) hipFree(c->d_prefilter);
