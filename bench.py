@@ -160,10 +160,12 @@ def main():
         except Exception:
             pass
         out = {
-            "metric": "bases/s through ntsmCount count path, 150 bp reads vs hs_n10_like (96287 sites)",
+            "metric": "bases/s (and reads/s) through ntsmCount, 150 bp reads vs human_sites_n10.fa",   # BASELINE.json's metric
             "value": value, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic (reads: counter-based generator; sites: hs_n10_like, a 96287-site stand-in with the geometry of "
+                    "data/human_sites_n10.fa, which the reference checkout does not contain)",
             "reads_per_s": world * n_reads * args.steps / elapsed,
             "config": {"workload": "configs[1]: %.3g synthetic 150 bp reads per GPU resident in HBM, hs_n10_like sites "
                                    "(96287 sites, %d distinct 19-mers), k=19" % (n_reads, len(sites.keys)),
