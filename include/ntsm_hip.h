@@ -92,8 +92,8 @@ int ntsm_set_batch_capacity(ntsm_ctx *ctx, uint64_t cap_bytes, uint64_t cap_read
 
 /* Producer lanes: SEVERAL host threads feeding ONE context -- the reference's `omp parallel for` over files with a
  * shared m_counts and `#pragma omp atomic` increments (src/FingerPrint.hpp:47, :94-99).  A lane is one thread's
- * private pair of pinned staging slots (cap_bytes of bases / cap_reads offsets each; 0 = the context's defaults)
- * with their own streams; every lane counts into the context's tables.  Calls on different lanes may run
+ * private pair of pinned staging slots (cap_bytes of bases / cap_reads offsets each; 0 = the context's defaults);
+ * the lanes of a context share its two lane streams and every lane counts into the context's tables.  Calls on different lanes may run
  * concurrently; one lane is driven by one thread.  acquire/submit behave like ntsm_staging_acquire /
  * ntsm_submit_staged.  close drains the lane and folds its totals into the context; ntsm_sync, ntsm_counts*,
  * ntsm_reset and ntsm_set_tuning return NTSM_ERR_STATE while a lane is open.  Lanes are refused
@@ -106,8 +106,8 @@ int ntsm_lane_submit(ntsm_lane *lane, uint64_t n_bytes, uint32_t n_reads);
 int ntsm_lane_close(ntsm_lane *lane);
 
 /* Initialise the HIP runtime and the device context of `device` and put `n_streams` ready-made streams into the
- * library's per-device stream pool (contexts take 3, every lane 1; streams go back to the pool when their owner is
- * destroyed).  Thread-safe.  Creating a stream costs ~14 ms on this runtime, so a host calls this on a side thread
+ * library's per-device stream pool (a context takes 3, plus 2 once it has lanes; streams go back to the pool when
+ * the context is destroyed).  Thread-safe.  Creating a stream costs ~14 ms on this runtime, so a host calls this on a side thread
  * while it loads the sites file (src/FingerPrint.hpp:489-572), before ntsm_create.  Optional: everything is
  * created on demand otherwise. */
 int ntsm_warmup(int device, int n_streams);

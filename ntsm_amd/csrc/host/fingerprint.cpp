@@ -39,11 +39,12 @@ void Feeder::die(int rc, const char *what) const
 }
 
 static std::mutex g_stderr;
-/* Staging slot of a producer lane (-t N): 16 MiB, less when many threads would pin more than 1 GiB in total */
+/* Staging slot of a producer lane (-t N): 8 MiB, less when many threads would pin more than 512 MiB in total
+ * (pinning costs 0.16 ms/MiB and competes with the table upload for the runtime's lock) */
 static uint64_t lane_bytes(unsigned threads)
 {
-	uint64_t b = 16ull << 20;
-	while (b > (2ull << 20) && 2ull * threads * b > (1ull << 30)) b >>= 1;
+	uint64_t b = 8ull << 20;
+	while (b > (1ull << 20) && 2ull * threads * b > (512ull << 20)) b >>= 1;
 	return b;
 }
 
@@ -153,7 +154,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 		if (std::find(m_ctxDevice.begin(), m_ctxDevice.end(), d) == m_ctxDevice.end()) m_ctxDevice.push_back(d);
 	/* Side threads, one per device, prepare everything that does not depend on the sites while this thread parses
 	 * them: runtime + device context, the three streams of a context, the pinned staging pool (first device),
-	 * one stream per producer lane.  They are joined when the first batch is about to be staged (computeCounts). */
+	 * the two streams its lanes share.  They are joined when the first batch is about to be staged (computeCounts). */
 	const auto tc0 = std::chrono::steady_clock::now();
 	{
 		const bool maybe_armed = m_opt.covThresh != 0 && m_opt.covThresh < 1e300;
@@ -166,9 +167,8 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 			const int d = m_ctxDevice[i];
 			const bool first = i == 0;
 			m_prep.emplace_back([d, first, pool_bytes, lanes_per_dev]() {
-				if (ntsm_warmup(d, 3) != NTSM_OK) return;           /* ntsm_create reports the failure */
+				if (ntsm_warmup(d, lanes_per_dev ? 5 : 3) != NTSM_OK) return;   /* a context's 3 streams + its 2 lane streams; ntsm_create reports failures */
 				if (first) (void) ntsm_staging_pool(pool_bytes);
-				(void) ntsm_warmup(d, lanes_per_dev);
 			});
 		}
 	}
@@ -270,8 +270,9 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 	std::vector<std::string> rest;
 	for (const std::string &fn : filenames) {
 		ParallelFastq pf;
-		/* a block's sequences (< half its bytes) must fit one lane slot: no waiting for the predecessor mid-block */
-		if (!pf.open(fn, std::min<uint64_t>(m_opt.block_bytes, lane_bytes(m_opt.threads)))) { rest.push_back(fn); continue; }
+		/* a block's sequences + terminators (at most half its bytes: a record is header + SEQ + '+' line + QUAL) must
+		 * fit one lane slot, so that no thread waits for its predecessor in the middle of a block */
+		if (!pf.open(fn, std::min<uint64_t>(m_opt.block_bytes, 2 * lane_bytes(m_opt.threads)))) { rest.push_back(fn); continue; }
 		const auto tp0 = std::chrono::steady_clock::now();
 		if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "block-parallel: " << pf.n_blocks() << " blocks, " << want << " threads" << std::endl;
 		std::vector<Feeder *> sinks;

@@ -7,6 +7,8 @@
  * threads are spread round-robin over the listed devices and the per-k-mer counts are summed on the host.
  */
 #include <getopt.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -141,7 +143,19 @@ int main(int argc, char *argv[])
 	if (const char *bb = getenv("NTSM_BATCH_BYTES")) opt.batch_bytes = strtoull(bb, nullptr, 10);   /* staging slot size */
 	if (const char *pb = getenv("NTSM_BLOCK_BYTES")) opt.block_bytes = strtoull(pb, nullptr, 10);   /* block-parallel ingest block size */
 	const auto t0 = std::chrono::steady_clock::now();
-	const bool phases = opt.phase_times = getenv("NTSM_PHASE_TIMES") != nullptr;     /* diagnostics: where the wall time goes */
+	const bool phases = opt.phase_times = getenv("NTSM_PHASE_TIMES") != nullptr;
+	if (phases) {                                          /* time between exec and main: loader + static initialisers of the HIP runtime */
+		std::ifstream st("/proc/self/stat");
+		std::string tok, all;
+		std::getline(st, all);
+		std::stringstream ss(all.substr(all.rfind(')') + 2));
+		unsigned long long start_ticks = 0;
+		for (int i = 3; i <= 22 && (ss >> tok); ++i) if (i == 22) start_ticks = strtoull(tok.c_str(), nullptr, 10);
+		struct timespec bt;
+		clock_gettime(CLOCK_BOOTTIME, &bt);
+		const double now = (double) bt.tv_sec + 1e-9 * (double) bt.tv_nsec;
+		std::cerr << "[phase] exec -> main: " << now - (double) start_ticks / (double) sysconf(_SC_CLK_TCK) << " s (clock-tick resolution)" << std::endl;
+	}     /* diagnostics: where the wall time goes */
 	auto lap = [&](const char *what) {
 		if (phases) std::cerr << "[phase] " << what << ": " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
 	};

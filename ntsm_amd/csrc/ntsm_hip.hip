@@ -664,8 +664,10 @@ struct ntsm_ctx {
 	uint64_t t_launches = 0;
 	double t_ms = 0;
 	/* producer lanes (ntsm_lane_*): several host threads feeding this context */
-	std::mutex mu;                             /* guards open_lanes, the lane totals fold-in and the timing pool */
+	std::mutex mu;                             /* guards open_lanes, lane_stream, the lane totals fold-in and the timing pool */
 	int open_lanes = 0;
+	hipStream_t lane_stream[2] = { nullptr, nullptr };   /* shared by all lanes (round robin): a stream costs 14 ms to create */
+	unsigned lanes_opened = 0;
 };
 
 /* One producer thread's private staging: two pinned slots + their device mirrors and streams.  All lanes of a
@@ -1195,6 +1197,7 @@ void ntsm_destroy(ntsm_ctx *c)
 		if (s.done) (void) hipEventDestroy(s.done);
 	}
 	stream_put(c->device, c->rstream);
+	for (hipStream_t st : c->lane_stream) stream_put(c->device, st);
 	for (int i = 0; i < kTimingPool; ++i) {
 		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
 		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
@@ -1309,18 +1312,26 @@ int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lan
 	l->c = c;
 	l->cap_bytes = cap_bytes;
 	l->cap_reads = cap_reads;
-	/* both slots share ONE stream: copy and kernel of a lane's consecutive batches run back to back, the overlap
-	 * comes from the other lanes (a stream is the expensive part of a lane) */
+	/* Lanes do not own streams (creating one costs 14 ms): all lanes of a context share its two lane streams, round
+	 * robin.  Copies and kernels of different lanes interleave there in submission order; a lane only waits on the
+	 * events of its own slots. */
+	hipStream_t st = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(c->mu);
+		hipStream_t &slot_stream = c->lane_stream[c->lanes_opened++ & 1u];
+		if (!slot_stream) slot_stream = stream_get(c->device);
+		st = slot_stream;
+	}
+	if (!st) { delete l; return NTSM_ERR_HIP; }
 	for (int i = 0; i < 2; ++i) {
 		Slot &s = l->slot[i];
-		if (i == 1) s.stream = l->slot[0].stream;
+		s.stream = st;
 		int rc = alloc_slot(s, c->device, cap_bytes, cap_reads, false);
 		if (rc) {
 			for (auto &q : l->slot) {
 				free_slot(q);
 				if (q.done) (void) hipEventDestroy(q.done);
 			}
-			stream_put(c->device, l->slot[0].stream);
 			delete l;
 			return rc;
 		}
@@ -1378,12 +1389,12 @@ int ntsm_lane_close(ntsm_lane *l)
 	ntsm_ctx *c = l->c;
 	int rc = NTSM_OK;
 	if (hipSetDevice(c->device) != hipSuccess) rc = NTSM_ERR_HIP;
-	if (l->slot[0].stream && hipStreamSynchronize(l->slot[0].stream) != hipSuccess) rc = NTSM_ERR_HIP;
-	for (auto &s : l->slot) {
+	for (auto &s : l->slot) {                            /* the stream is shared: wait for this lane's own batches only */
+		if (s.busy && hipEventSynchronize(s.done) != hipSuccess) rc = NTSM_ERR_HIP;
+		s.busy = false;
 		free_slot(s);
 		if (s.done) (void) hipEventDestroy(s.done);
 	}
-	stream_put(c->device, l->slot[0].stream);
 	{
 		std::lock_guard<std::mutex> lk(c->mu);
 		c->total_bases += l->total_bases;

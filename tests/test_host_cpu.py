@@ -5,6 +5,7 @@ import glob
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -509,3 +510,45 @@ def test_bgzf_block_parallel_inflate(nt, tmp_path):
     nt.capi.HO.ntsm_host_gunzip                                    # (decoder thread count is process-wide: set through the hook)
     got = nt.flatten_file(p)
     assert np.array_equal(plain[0], got[0]) and np.array_equal(plain[1], got[1])
+
+
+def test_parallel_site_loading_equals_sequential(nt, tmp_path):
+    """Site files that are plain two-line FASTA are k-merised by several threads (site_set.cpp); keys, allele lists,
+    IDs and the order of the collision warnings must equal the sequential kseq-equivalent load; anything else (CRLF,
+    wrapped sequence, gzip, FASTQ, junk first) takes the sequential path and still agrees."""
+    import gzip
+    import subprocess
+    sp = str(tmp_path / "s.fa")
+    nt.SynthShort(sites_seed=3, n_sites=8000, read_seed=1, sites_path=sp)      # ~2.8 MB, 16000 records
+    raw = open(sp, "rb").read()
+    assert len(raw) > (1 << 20)
+    lines = raw.split(b"\n")
+    dup = b"\n".join(lines[:400]) + b"\n"                           # repeat 200 records at the end: duplicate k-mers, warnings
+    variants = {"plain.fa": raw, "dups.fa": raw + dup, "crlf.fa": raw.replace(b"\n", b"\r\n"),
+                "wrapped.fa": b"\n".join(l if i % 2 == 0 or len(l) < 30 else l[:25] + b"\n" + l[25:] for i, l in enumerate(lines)),
+                "junk.fa": b"# comment\n" + raw, "noeol.fa": raw[:-1], "empty_seq.fa": raw + b">x\n\n>y\nACGTACGTACGTACGTACGTACGT\n"}
+    # one subprocess per file (the warnings go to the process's stderr): four loads, markers in between
+    code = ("import os, sys; sys.path.insert(0, %r); import numpy as np, ntsm_amd, hashlib\n"
+            "for dupes in (False, True):\n"
+            "    for seq in (False, True):\n"
+            "        os.environ.pop('NTSM_SITES_SEQUENTIAL', None)\n"
+            "        if seq: os.environ['NTSM_SITES_SEQUENTIAL'] = '1'\n"
+            "        s = ntsm_amd.Sites(sys.argv[1], allow_dupes=dupes)\n"
+            "        c = (np.arange(len(s.keys), dtype=np.uint64) * 7 + 3) %% 41; rc, txt = s.format_counts(c, 12345)\n"
+            "        print(len(s.keys), s.n_sites, s.n_erased, rc, hashlib.sha256(s.keys.tobytes()).hexdigest(), hashlib.sha256(txt).hexdigest(), flush=True)\n"
+            "        sys.stderr.write('==MARK==\\n'); sys.stderr.flush()\n") % ROOT
+    for name, data in variants.items():
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        r = subprocess.run([sys.executable, "-c", code, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        res = r.stdout.split(b"\n")[:4]
+        warn = [[l for l in part.split(b"\n") if l.startswith(b"Warning")] for part in r.stderr.split(b"==MARK==\n")[:4]]
+        assert res[0] == res[1] and res[2] == res[3] and warn[0] == warn[1] and warn[2] == warn[3], name
+        if name == "dups.fa":
+            assert len(warn[0]) > 1000 and warn[0] == warn[2]       # the collision warnings are there, in the same order
+    gz = str(tmp_path / "s.fa.gz")
+    with gzip.open(gz, "wb", compresslevel=1) as f:
+        f.write(raw)
+    a, b = nt.Sites(sp), nt.Sites(gz)
+    assert np.array_equal(a.keys, b.keys) and a.n_sites == b.n_sites
