@@ -76,12 +76,13 @@ void GzStream::set_decoder_threads(unsigned n) { g_decoder_threads = n < 1 ? 1 :
 
 bool GzStream::is_gzip(const std::string &path)
 {
+	struct stat st;
+	/* stat before open: opening and closing a FIFO or a /dev/fd pipe just to look at it can end its writer */
+	if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) return false;
 	const int fd = ::open(path.c_str(), O_RDONLY);
 	if (fd < 0) return false;
-	struct stat st;
 	unsigned char magic[2] = { 0, 0 };
-	const bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 2 && pread(fd, magic, 2, 0) == 2 &&
-	                magic[0] == 0x1f && magic[1] == 0x8b;
+	const bool ok = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
 	::close(fd);
 	return ok;
 }

@@ -23,7 +23,9 @@
 
 #define PROGRAM "ntsmCount"
 
-static bool fexists(const std::string &fn) { std::ifstream f(fn.c_str()); return f.good(); }   /* src/Util.h:24-29 */
+/* src/Util.h:24-29 opens the file with an ifstream to see whether it is readable; access() answers the same question
+ * without opening it, which matters for FIFOs and process substitution (an extra open/close can end the writer) */
+static bool fexists(const std::string &fn) { return access(fn.c_str(), R_OK) == 0; }
 
 static size_t rss_kb()                                  /* src/Util.h:32-49 */
 {

@@ -19,10 +19,10 @@ ParallelFastq::~ParallelFastq()
 bool ParallelFastq::open(const std::string &path, uint64_t block_bytes)
 {
 	if (block_bytes < 4096) block_bytes = 4096;
+	struct stat st;                                                       /* stat before open: never touch a FIFO / pipe here */
+	if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || (uint64_t) st.st_size < 2 * block_bytes) return false;   /* small: not worth it */
 	m_fd = ::open(path.c_str(), O_RDONLY);
 	if (m_fd < 0) return false;
-	struct stat st;
-	if (fstat(m_fd, &st) != 0 || !S_ISREG(st.st_mode) || (uint64_t) st.st_size < 2 * block_bytes) return false;   /* small: not worth it */
 	m_size = (uint64_t) st.st_size;
 	void *m = mmap(nullptr, m_size, PROT_READ, MAP_PRIVATE, m_fd, 0);
 	if (m == MAP_FAILED) return false;

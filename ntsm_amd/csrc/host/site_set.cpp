@@ -66,10 +66,10 @@ struct Occurrences {
 bool parallel_two_line_fasta(const std::string &path, unsigned k, std::vector<Occurrences> &parts)
 {
 	if (getenv("NTSM_SITES_SEQUENTIAL")) return false;        /* tests: force the sequential reader */
+	struct stat st;                                            /* stat before open: never touch a FIFO / pipe here */
+	if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < (1 << 20)) return false;
 	const int fd = open(path.c_str(), O_RDONLY);
 	if (fd < 0) return false;
-	struct stat st;
-	if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < (1 << 20)) { close(fd); return false; }
 	const size_t size = (size_t) st.st_size;
 	void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
 	close(fd);

@@ -552,3 +552,32 @@ def test_parallel_site_loading_equals_sequential(nt, tmp_path):
         f.write(raw)
     a, b = nt.Sites(sp), nt.Sites(gz)
     assert np.array_equal(a.keys, b.keys) and a.n_sites == b.n_sites
+
+
+def test_reader_on_a_fifo(nt, tmp_path):
+    """Input through a named pipe (e.g. `ntsmCount -s sites.fa <(zcat x.fq.gz)`): the file is opened exactly once --
+    the gzip / block-parallel eligibility checks only stat() it -- and parses like the regular file, plain and gzip."""
+    import gzip
+    import threading
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=8, p_embed=0.2)
+    fq = str(tmp_path / "f.fq")
+    s.write_fastq(fq, 0, 4000)
+    raw = open(fq, "rb").read()
+    want = nt.flatten_file(fq)
+    for blob in (raw, gzip.compress(raw, 1)):
+        fifo = str(tmp_path / "pipe")
+        if os.path.exists(fifo):
+            os.unlink(fifo)
+        os.mkfifo(fifo)
+        opened = []
+
+        def writer():
+            with open(fifo, "wb") as f:                      # blocks until the reader opens; a second open would hang or break it
+                opened.append(1)
+                f.write(blob)
+        th = threading.Thread(target=writer)
+        th.start()
+        got = nt.flatten_file(fifo)
+        th.join(timeout=30)
+        assert not th.is_alive() and opened == [1]
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
