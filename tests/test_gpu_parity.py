@@ -651,6 +651,20 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
         assert fp.total_hits > 100
 
 
+def test_cli_reads_from_pipes(nt):
+    """`ntsmCount -s sites.fa <(zcat a.fq.gz) <(cat b.fq)`: inputs that are pipes (process substitution) give the bytes
+    of the same run on the files, with -t 1 and -t 2."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    inp = os.path.join(G, "inputs")
+    base = subprocess.run([exe, "-s", "sites200.fa", "reads600.fq.gz", "reads2k.fq"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert base.returncode == 0
+    for t in ("1", "2"):
+        p = subprocess.run(["bash", "-c", exe + " -s sites200.fa -t " + t + " <(zcat reads600.fq.gz) <(cat reads2k.fq)"], cwd=inp,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr[-400:]
+        assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr)
+
+
 def test_randomised_cli_soak(nt):
     """tools/soak.py for 20 s: random site sets / k / FASTQ-FASTA-gzip-BGZF inputs (ragged reads, Ns, lower case, CRLF,
     wrapped records) and random -t / -d / -m / staging and block sizes: the CLI's stdout equals the oracle's byte for
