@@ -153,10 +153,11 @@ def main():
         launch_s = kernel_ms / 1e3 / max(n_launch, 1)
         bytes_per_base = (READ_LEN + 8) / READ_LEN
         achieved = bases_per_step * bytes_per_base / launch_s / 1e9
-        traffic = None                          # PMC-derived bytes per launch (separate rocprofv3 --pmc passes, profiles/)
+        traffic = valu_busy = None              # PMC-derived (separate rocprofv3 --pmc passes, profiles/): bytes per launch, VALU share
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             traffic = tj["traffic_bytes_per_base"] * bases_per_step
+            valu_busy = tj.get("valu_busy_frac")
         except Exception:
             pass
         out = {
@@ -178,6 +179,7 @@ def main():
                          "achieved_stream_only_GBs": bases_per_step * (READ_LEN + 1) / READ_LEN / launch_s / 1e9,
                          "kernel": "ntsm_count_k19_kernel" if K == 19 and not args.kernel else "ntsm_count_kernel", "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
                          "algorithmic_bytes_per_base": bytes_per_base,
+                         "valu_busy_frac_from_pmc": valu_busy,     # the resource that actually binds: share of SIMD issue cycles on VALU
                          "kmer_probe_rate_per_s": totals.total_kmers / max(args.steps + args.warmup, 1) / launch_s},
             "check": {"total_kmers_per_step": totals.total_kmers // (args.steps + args.warmup) if world == 1 else None,
                       "total_hits_per_step": totals.total_hits // (args.steps + args.warmup) if world == 1 else None},
