@@ -672,3 +672,25 @@ def test_randomised_cli_soak(nt):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "20", "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
     assert b"0 mismatches" in p.stdout
+
+
+def test_bench_contract_line(nt):
+    """bench.py at a small size: exactly one JSON line with the contract's keys (metric/value/unit/..., roofline,
+    cpu_baseline from the CPU reference or its port), and the per-step totals it reports are the oracle-checked ones
+    scaled: value = bases / time, frac = achieved / peak."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2e6", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-1500:]
+    lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "bases/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches"] == 2
+    assert abs(d["value"] - 2e6 * 150 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == "bases/s" and 1e6 < c["value"] < 1e9
