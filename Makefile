@@ -28,8 +28,12 @@ build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp 
 	$(CXX) $(CXXFLAGS) -o $@ $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp \
 	    -Lntsm_amd -lntsm_hip -lz -pthread -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
-ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_device.h include/ntsm_hip.h
+ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ntsm_hip.hip -ldl
+
+# ablation builds of the tabulated kernel for tools/ab_libs.sh (never shipped: wrong counts by construction)
+ablation: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h
+	for a in $(or $(ABL),1 2 4 5 7 8); do $(HIPCC) $(HIPFLAGS) -DNTSM_ABLATION -DNTSM_TAB_ABL=$$a -shared -o ntsm_amd/libntsm_hip_abl$$a.so $(CSRC)/ntsm_hip.hip -ldl & done; wait
 
 ntsm_amd/libntsm_synth.so: $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp -lz
@@ -48,4 +52,4 @@ build/gather_bench: tools/gather_bench.hip
 clean:
 	rm -rf build ntsm_amd/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle_all clean
+.PHONY: all oracle_all clean ablation

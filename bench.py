@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter-log2", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto (fast path for k=19), 1 generic")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (minimizer-blocked kernel for k=19), 1 generic, 3 tabulated")
+    ap.add_argument("--no-check", action="store_true", help="skip the sum-of-pieces correctness check of the timed result")
     args = ap.parse_args()
 
     import torch
@@ -125,6 +126,20 @@ def main():
         if use_dist:
             merge_counts(ctx)
 
+    # Correctness of the timed launch at full size (byte offsets far beyond 2^32): the same resident stream counted in
+    # read-aligned pieces of < 2 GiB on a second context, each piece re-based so that its offsets are small.  The timed
+    # context must reproduce these totals and per-k-mer counts exactly (checked after the timed region).
+    expect = None
+    if not args.no_check and not use_dist:
+        ref = ntsm_amd.Context(sites.keys, k=K, device=local)
+        piece = 13_000_000 // 16 * 16                     # 1.96 GB; a multiple of 16 reads keeps the piece bases 16-byte aligned
+        for r0 in range(0, n_reads, piece):
+            m = min(piece, n_reads - r0)
+            ref.count_resident(d_bases.data_ptr() + r0 * synth.stride, m * synth.stride, 0, m)
+        tr = ref.sync()
+        expect = (tr.total_kmers, tr.total_hits, ref.counts())
+        ref.close()
+
     for _ in range(args.warmup):
         run_step()
     ctx.sync()
@@ -142,6 +157,13 @@ def main():
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = ctx.get_timing()
     totals = ctx.sync()
+    checked = False
+    if expect is not None:
+        reps = args.steps + args.warmup
+        assert (totals.total_kmers, totals.total_hits) == (reps * expect[0], reps * expect[1]), \
+            "timed launches disagree with the sum over < 2 GiB pieces: %r vs %d x %r" % ((totals.total_kmers, totals.total_hits), reps, expect[:2])
+        assert (ctx.counts() == expect[2] * reps).all(), "per-k-mer counts of the timed launches differ from the sum over pieces"
+        checked = True
 
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -171,18 +193,21 @@ def main():
             "config": {"workload": "configs[1]: %.3g synthetic 150 bp reads per GPU resident in HBM, hs_n10_like sites "
                                    "(96287 sites, %d distinct 19-mers), k=19" % (n_reads, len(sites.keys)),
                        "reads_per_gpu": n_reads, "read_len": READ_LEN, "k": K, "n_sites": N_SITES,
-                       "parallelism": "reads sharded over %d GPU(s); one RCCL SUM of per-k-mer counts per step" % world},
+                       "parallelism": ("reads sharded over %d GPUs; one RCCL SUM of per-k-mer counts per step" % world) if world > 1
+                                      else "one GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "fabric-side bytes/launch from FETCH_SIZE+WRITE_SIZE (profiles/r01_traffic.json): L2 misses "
                                          "of filter/table served by the Infinity Cache + the stream; not HBM re-reads",
                          "achieved_stream_only_GBs": bases_per_step * (READ_LEN + 1) / READ_LEN / launch_s / 1e9,
-                         "kernel": "ntsm_count_k19_kernel" if K == 19 and not args.kernel else "ntsm_count_kernel", "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
+                         "kernel": {0: "ntsm_count_k19_kernel", 2: "ntsm_count_k19_kernel", 3: "ntsm_count_tab19_kernel"}.get(args.kernel, "ntsm_count_kernel"),
+                         "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
                          "algorithmic_bytes_per_base": bytes_per_base,
                          "valu_busy_frac_from_pmc": valu_busy,     # the resource that actually binds: share of SIMD issue cycles on VALU
                          "kmer_probe_rate_per_s": totals.total_kmers / max(args.steps + args.warmup, 1) / launch_s},
             "check": {"total_kmers_per_step": totals.total_kmers // (args.steps + args.warmup) if world == 1 else None,
-                      "total_hits_per_step": totals.total_hits // (args.steps + args.warmup) if world == 1 else None},
+                      "total_hits_per_step": totals.total_hits // (args.steps + args.warmup) if world == 1 else None,
+                      "equals_sum_of_pieces_below_2GiB": checked},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(synth, sites_path, args.cpu_sample_reads)

@@ -154,9 +154,16 @@ int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
 /* Tuning knobs (0 = automatic): log2 of filter bits (rebuilds the tables: counts and totals restart from zero),
  * grid blocks.  For profiling experiments. */
 int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
-/* Kernel choice: 0 = automatic (minimizer-blocked fast path when k == 19, generic otherwise),
- * 1 = always the generic kernel.  Both give identical results; for A/B measurements. */
+/* Kernel choice: 0 = automatic (k == 19: the minimizer-blocked kernel; other k: the generic kernel), 1 = always the
+ * generic kernel, 2 = same as 0, 3 = k == 19 only: the tabulated kernel (table-driven hashes, 2-bit packed tiles, look-up
+ * kernel on a second stream; the minimizer-blocked kernel still takes tiles that hold bytes outside ACGTUNacgtun and -m
+ * batches).  All give identical results; 3 is measured 7 % slower than 0 on the bench workload. */
 int ntsm_set_kernel(ntsm_ctx *ctx, int variant);
+/* Introspection for tests and profiles (implies a sync): out[0] = 64 KiB tiles the tabulated kernel handed to the
+ * exact kernel because they hold bytes outside ACGTUNacgtun, out[1..3] = count launches by kernel
+ * (tabulated, minimizer-blocked, generic), out[4] = windows that passed the tabulated kernel's first-level filter and
+ * were queued for the look-up kernel (since creation or the last ntsm_reset), out[5..7] = 0 (reserved). */
+int ntsm_debug_stats(ntsm_ctx *ctx, uint64_t out[8]);
 /* The HIP stream (hipStream_t) ntsm_count_resident launches on. */
 void *ntsm_stream(ntsm_ctx *ctx);
 

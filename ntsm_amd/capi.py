@@ -78,6 +78,7 @@ _sig(H, "ntsm_get_timing", C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_double)])
 _sig(H, "ntsm_set_tuning", C.c_int, [C.c_void_p, C.c_int, C.c_int])
 _sig(H, "ntsm_set_kernel", C.c_int, [C.c_void_p, C.c_int])
 _sig(H, "ntsm_stream", C.c_void_p, [C.c_void_p])
+_sig(H, "ntsm_debug_stats", C.c_int, [C.c_void_p, u64p])
 _sig(H, "ntsm_hash64", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_hash64_inv", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_strerror", C.c_char_p, [C.c_int])
@@ -292,6 +293,13 @@ class Context:
 
     def set_kernel(self, variant):
         _chk(H.ntsm_set_kernel(self._h, int(variant)), "ntsm_set_kernel")
+
+    def debug_stats(self):
+        """dict(exotic_tiles, launches_tab, launches_k19, launches_generic) -- include/ntsm_hip.h ntsm_debug_stats"""
+        out = np.zeros(8, dtype=np.uint64)
+        _chk(H.ntsm_debug_stats(self._h, _p(out, u64p)), "ntsm_debug_stats")
+        return dict(exotic_tiles=int(out[0]), launches_tab=int(out[1]), launches_k19=int(out[2]), launches_generic=int(out[3]),
+                    queued_windows=int(out[4]))
 
     @property
     def stream(self):

@@ -80,6 +80,10 @@ public:
 		Result r;
 		r.complete = m_failBlock == kNoFail;
 		r.resume = r.complete ? m_size : m_resume;
+		if (r.complete && m_nBlocks && m_end[m_nBlocks - 1] != m_size) {   /* invariant: complete <=> the last block ended at EOF */
+			r.complete = false;
+			r.resume = m_end[m_nBlocks - 1];
+		}
 		r.records = records;
 		return r;
 	}
@@ -108,8 +112,15 @@ private:
 		if (m_failBlock.load(std::memory_order_relaxed) < b) return 0;   /* the parallel phase already stopped before this block */
 		const uint64_t first = b == 0 ? 0 : find_start(lo, hi);
 		s.begin_block(b);
-		if (first == kNone) {                                 /* a record longer than the block runs through it */
-			if (wait_start(b, kNone, &prev_end)) publish(b, prev_end);
+		if (first == kNone) {
+			/* No strict record starts in this block.  Either a record longer than the block runs through it
+			 * (b-1 ended at or beyond hi: pass that end on), or b-1 ended INSIDE this block, i.e. a record begins
+			 * here that does not parse as strict (wrapped, CRLF, no newline at the end of the file ...): the
+			 * parallel phase stops at that record and the sequential reader takes over. */
+			if (wait_start(b, kNone, &prev_end)) {
+				if (prev_end < hi) fail(b, prev_end);
+				else publish(b, prev_end);
+			}
 			return 0;
 		}
 		const char *const e = m_data + m_size, *const lim = m_data + hi;

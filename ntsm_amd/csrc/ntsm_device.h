@@ -90,6 +90,86 @@ NTSM_DHD uint32_t ntsm_kmer_mix(uint32_t u) { return u * 0x9E3779B1u; }
 /* a minimizer value that no 12-mer produces (0x9E3779 * 2^24 mod 2^32): "no block cached yet" */
 #define NTSM_NO_MINIMIZER 0x79000000u
 
+
+/* ---- k = 19 tabulated path ("tab" kernel) ------------------------------------
+ * Measured on gfx950 (profiles/r02_valu_rate.txt): every wave64 VALU instruction of a mixed stream occupies its
+ * SIMD for ~4.2 cycles whatever the opcode and whatever the occupancy, so the count kernel's speed is its VALU
+ * instruction count.  This path therefore computes nothing per base that a table can supply:
+ *   - the stream is 2-bit packed while it is staged (16 bases per word, first base in the low bits);
+ *   - a 256-entry LDS table indexed by the 4-mer ending at position p returns { U, V, M, - };
+ *   - order key of the 12-mer ending at i:  K(i) = U[e4(i-8)] + M[e4(i-4)] + V[e4(i)]   (one v_add3_u32);
+ *   - bit-selection hash of the 19-mer ending at i:  h(i) = V[e4(i)] + U[e4(i-15)]       (one v_add_u32).
+ * Strand symmetry needs no reverse complement at run time: with V[y] = U[rc(y)] and M[y] = M[rc(y)] both sums are
+ * invariant under (a, b, c) -> (rc c, rc b, rc a) because addition commutes (XOR would map every palindromic
+ * 12-mer to 0: measured 456 site k-mers in one block instead of 64).  The minimizer is the smallest K among the 8
+ * 12-mers of the 19-mer; its LOW bits (uniform, independent of the order statistic) address a 128-bit block; the
+ * four bytes of h give one bit position in each 32-bit word.  False-positive rate on hs_n10_like at 3 MiB: 1.44 %
+ * (tools/sim_tab_filter.py; ideal random hashes of the canonical codes: 1.18 %). */
+struct NtsmTabEntry { uint32_t u, v, m, pad; };
+#define NTSM_TAB_SEED 0x6A09E667F3BCC909ULL
+
+NTSM_DHD uint64_t ntsm_splitmix(uint64_t *s)
+{
+	uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+/* reverse complement of a 4-mer index (first base in bits 0-1) */
+NTSM_DHD uint32_t ntsm_rc4(uint32_t y)
+{
+	const uint32_t c = ~y & 0xFFu;
+	return ((c & 3u) << 6) | ((c & 0xCu) << 2) | ((c >> 2) & 0xCu) | (c >> 6);
+}
+static inline void ntsm_tab_build(struct NtsmTabEntry *t /* [256] */)
+{
+	uint32_t a[256], c[256], b[256];
+	uint64_t s = NTSM_TAB_SEED;
+	for (int i = 0; i < 256; ++i) { a[i] = (uint32_t) ntsm_splitmix(&s); c[i] = (uint32_t) ntsm_splitmix(&s); b[i] = (uint32_t) ntsm_splitmix(&s); }
+	for (uint32_t y = 0; y < 256; ++y) {
+		const uint32_t r = ntsm_rc4(y);
+		t[y].u = a[y] ^ c[r];
+		t[y].v = c[y] ^ a[r];                 /* = u[rc y] */
+		t[y].m = b[y] + b[r];                 /* = m[rc y] */
+		t[y].pad = 0;
+	}
+}
+/* order key of the minimizer and bit-selection hash of a 19-mer given as its canonical (or any strand's) big-endian
+ * 2-bit code: what the kernel computes from the packed stream, restated on the code for the table builder */
+static inline void ntsm_tab_kmer(const struct NtsmTabEntry *t, uint64_t code, uint32_t *mz_out, uint32_t *h_out)
+{
+	uint32_t e4[19];                          /* e4[p]: index of the 4-mer ending at base p (p >= 3) */
+	for (int p = 3; p < 19; ++p) {
+		uint32_t y = 0;
+		for (int q = 0; q < 4; ++q) y |= (uint32_t) ((code >> (2 * (18 - (p - 3 + q)))) & 3u) << (2 * q);
+		e4[p] = y;
+	}
+	uint32_t mz = 0xFFFFFFFFu;
+	for (int p = 11; p < 19; ++p) {
+		const uint32_t k = t[e4[p - 8]].u + t[e4[p - 4]].m + t[e4[p]].v;
+		if (k < mz) mz = k;
+	}
+	*mz_out = mz;
+	*h_out = t[e4[18]].v + t[e4[3]].u;
+}
+/* byte offset of the 128-bit block of a minimizer key.  n_blocks = mult * 2^e, mult in {1, 3}.  Only LOW bits of the
+ * key are used: they are uniform and independent of the order statistic (the top bits of a minimum are not).
+ *   mult = 1: bits 4 .. e+3 of the key in place                      (one v_and_b32; mask = (2^e - 1) << 4)
+ *   mult = 3: ((low 24 bits * 3) >> (20 - e)) & ~15, e <= 20          (v_mul_u32_u24, v_lshrrev_b32, v_and_b32) */
+struct NtsmTabMap { uint32_t mask, shift, mult3; };
+NTSM_DHD uint32_t ntsm_tab_block_off(uint32_t mz, NtsmTabMap m)
+{
+	if (!m.mult3) return mz & m.mask;
+#if defined(__HIP_DEVICE_COMPILE__)
+	return ((uint32_t) __umul24(mz, 3u) >> m.shift) & ~15u;
+#else
+	return (((mz & 0xFFFFFFu) * 3u) >> m.shift) & ~15u;
+#endif
+}
+/* bit tested in word w of the block: (31 - ((h >> 8w) & 31)); the kernel shifts the word LEFT by (h >> 8w) & 31 and
+ * reads the sign bit */
+NTSM_DHD uint32_t ntsm_tab_bit(uint32_t h, int w) { return 31u - ((h >> (8 * w)) & 31u); }
+
 struct NtsmCountParams {
 	const uint8_t *base;               /* 16-byte aligned start of the flat stream */
 	long long lo, hi;                  /* count windows ending at byte offsets in [lo, hi) */
@@ -114,6 +194,21 @@ struct NtsmCountParams {
 	uint32_t pf_shift;                 /* word index = h1(fold) >> pf_shift; bits = h2(fold) & 31, (h2 >> 5) & 31 */
 	uint32_t debug;                    /* ablation switches (NTSM_DEBUG_KERNEL): 1 = drain discards its queue, 2 = drain stops after the k-mer rebuild */
 	uint32_t blk_bytes;                /* size of the filter in bytes (buffer descriptor range) */
+	/* tabulated k = 19 path */
+	const NtsmTabEntry *tab;           /* 256 entries, copied to LDS by every workgroup */
+	const uint4 *tblocks;              /* its minimizer-addressed 128-bit filter blocks */
+	uint32_t tblk_bytes;
+	NtsmTabMap tblk_map;
+	uint32_t *exotic_list;             /* tab kernel: appends the 32 KiB tiles it skipped (bytes outside ACGTUNacgtun) ... */
+	uint32_t *exotic_count;            /* ... and the list's fill; the k19 kernel launched behind it counts exactly those tiles */
+	uint32_t exotic_cap;
+	uint32_t *exotic_seen;             /* statistics: tiles handed over since the context was created */
+	uint32_t use_list;                 /* k19 kernel: walk exotic_list instead of all tiles */
+	/* tab kernel -> look-up kernel: canonical codes of the windows that passed the first-level filter */
+	unsigned long long *pos_queue;     /* [pos_cap] */
+	uint32_t *pos_count;               /* entries reserved in this segment's queue (may exceed pos_cap: the rest was looked up in line) */
+	uint32_t pos_cap;
+	unsigned long long tile_base;      /* tab kernel: index of this segment's first 64 KiB tile within the launch (exotic list entries are global) */
 };
 
 #endif

@@ -259,14 +259,33 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			const_cast<uint4 *>(p.blocks), 0, (int) p.blk_bytes, 0x00020000);
 	uint32_t nk = 0, nh = 0;
 
-	for (unsigned long long ti = blockIdx.x; ti < p.n_tiles; ti += gridDim.x) {
+	/* list mode: only the tiles the tabulated kernel handed over (tiles with bytes outside ACGTUNacgtun) */
+	const unsigned long long n_iter = p.use_list ? (unsigned long long) min(*p.exotic_count, p.exotic_cap) : p.n_tiles;
+	for (unsigned long long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+		const unsigned long long ti = p.use_list ? (unsigned long long) p.exotic_list[it] : it;
+		if (ti >= p.n_tiles) continue;
 		const long long ts = p.t0 + (long long) (ti * (unsigned long long) (kThreads * C));
 		__syncthreads();
+		if (ts >= p.lo && ts + kThreads * C <= p.hi) {
+			/* interior tile: plain coalesced loads (the boundary logic of ntsm_load_vec costs ~100 VALU instructions per
+			 * vector, 6.5 per base position -- a sixth of this kernel's instruction count when it ran for every tile) */
 #pragma unroll
-		for (int q = 0; q < VPT; ++q) {
-			const int v = t + kThreads * q;
-			const uint4 r = ntsm_load_vec(p, ts + 16ll * v);
-			*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr(1 + v / VPT, (v % VPT) * 16)) = r;
+			for (int q = 0; q < VPT; ++q) {
+				const int v = t + kThreads * q;
+#if NTSM_STREAM_NT
+				const u32x4 nt = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p.base + ts + 16ll * v));
+#else
+				const u32x4 nt = *reinterpret_cast<const u32x4 *>(p.base + ts + 16ll * v);
+#endif
+				*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr(1 + v / VPT, (v % VPT) * 16)) = make_uint4(nt.x, nt.y, nt.z, nt.w);
+			}
+		} else {
+#pragma unroll 1
+			for (int q = 0; q < VPT; ++q) {
+				const int v = t + kThreads * q;
+				const uint4 r = ntsm_load_vec(p, ts + 16ll * v);
+				*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr(1 + v / VPT, (v % VPT) * 16)) = r;
+			}
 		}
 		if (t < 2) {
 			const uint4 r = ntsm_load_vec(p, ts - 32 + 16 * t);
@@ -336,14 +355,19 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 					else if (bb.z == s2_klo && bb.w == s2_khi) slot = (long long) b2 + 1;
 				}
 				if (slot >= 0) {
+#ifdef NTSM_ABLATION
 					if (!(p.debug & 4u))
+#endif
 						__hip_atomic_fetch_add(ntsm_count_ptr(p.keys, slot), p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					++nh;
 					if (PER_READ) atomicAdd(p.read_hits + ntsm_read_of(p, (unsigned long long) (ts + (long long) s2_pos)), 1u);
 				}
 			}
 			/* stage 2 */
-			s2_v = s1_v && (((s1_pw >> (s1_g2 & 31u)) & (s1_pw >> ((s1_g2 >> 5) & 31u)) & 1u) != 0) && !(p.debug & 2u);
+			s2_v = s1_v && (((s1_pw >> (s1_g2 & 31u)) & (s1_pw >> ((s1_g2 >> 5) & 31u)) & 1u) != 0);
+#ifdef NTSM_ABLATION
+			s2_v = s2_v && !(p.debug & 2u);
+#endif
 			if (s2_v) {
 				s2_klo = s1_klo; s2_khi = s1_khi; s2_g2 = s1_g2; s2_pos = s1_pos;
 				s2_b1 = 2ull * (s1_g1 >> bshift);
@@ -354,7 +378,10 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 			if (take) {
 				const uint32_t n = qn < 64 ? qn : 64;
 				qn -= n;
-				s1_v = (uint32_t) lane < n && !(p.debug & 1u);
+				s1_v = (uint32_t) lane < n;
+#ifdef NTSM_ABLATION
+				s1_v = s1_v && !(p.debug & 1u);
+#endif
 				if (s1_v) {
 					/* rebuild both 38-bit strands from the two 16-base words: the forward code is the first 16
 					 * bases followed by the last 3 (complement-reversed top 3 groups of the reverse word), the
@@ -474,6 +501,8 @@ __global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kern
 	}
 }
 
+#include "ntsm_tab_kernel.inc"
+
 /* dense[i] = count of slot_of[i]; tail = totals */
 __global__ void ntsm_gather_kernel(const uint64_t *table, const uint32_t *slot_of, uint32_t n, unsigned long long *dense)
 {
@@ -510,6 +539,19 @@ static thread_local int g_last_hip = 0;
 namespace {
 
 constexpr int kTileC = 128;                 /* stream bytes per thread and tile */
+#ifndef NTSM_TABLE_LOAD
+#define NTSM_TABLE_LOAD 0.4                    /* cuckoo key table: slots >= keys / load, power of two */
+#endif
+#ifndef NTSM_TAB_SEG_TILES
+#define NTSM_TAB_SEG_TILES 16384
+#endif
+#ifndef NTSM_LOOK_WGS
+#define NTSM_LOOK_WGS 256                       /* look-up workgroups per launch */
+#endif
+#ifndef NTSM_TAB_TILES_PER_WG
+#define NTSM_TAB_TILES_PER_WG 1
+#endif
+constexpr uint64_t kTabSegTiles = NTSM_TAB_SEG_TILES;    /* tabulated path: 64 KiB tiles per launch segment (1 GiB); its look-up kernel runs beside the next segment */
 constexpr int kTimingPool = 256;
 
 /* Process-wide pool of pinned host memory (ntsm_staging_pool): pinning costs ~0.4 ms/MiB and the driver serialises
@@ -643,7 +685,24 @@ struct ntsm_ctx {
 	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
 	uint32_t prefilter_log2 = 0;               /* log2(bits) */
 	NtsmBlockMap blk_map = { 0, 1, 0 };
-	int kernel_variant = 0;                    /* 0 auto (fast path when k == 19), 1 generic */
+	/* tabulated k = 19 path (ntsm_tab_kernel.inc) */
+	NtsmTabEntry *d_tab = nullptr;
+	uint4 *d_tblocks = nullptr;
+	uint64_t n_tblocks = 0;
+	NtsmTabMap tblk_map = { 0, 0, 0 };
+	bool tab_ok = false;                       /* filter built and no site k-mer has the reserved minimizer key */
+	/* per launch stream, tabulated path: d_ctl = { [0] fill of the exotic-tile list of the launch in flight, [1 .. 1+2*seg_cap)
+	 * fills of the look-up queue slots (tile, wave), two halves, [1+2*seg_cap] exotic tiles seen so far, then the exotic list };
+	 * d_queue = canonical codes handed from the tabulated kernel to the look-up kernel (one segment at a time) */
+	struct StreamBuf {
+		hipStream_t stream; uint32_t *d_ctl; uint64_t seg_cap, exotic_cap; unsigned long long *d_queue; uint64_t queue_cap;
+		hipEvent_t ev_tab[2], ev_look[2];          /* two halves of queue + fills: segment s uses half s & 1 */
+	};
+	std::vector<StreamBuf> sbuf;
+	int look_blocks = 0;                       /* tuning: look-up workgroups per CU (0 = 1) */
+	hipStream_t lstream = nullptr;             /* the look-up kernels of all launch streams run here, beside the next segment's scan */
+	uint64_t n_launch[3] = { 0, 0, 0 };         /* count launches by kernel: tabulated, minimizer-blocked, generic */
+	int kernel_variant = 0;                    /* 0 auto (minimizer-blocked kernel when k == 19), 1 generic, 2 = 0, 3 tabulated k = 19 kernel */
 	std::vector<uint64_t> canon;               /* host copy of the canonical keys */
 	std::vector<uint32_t> slot_of;
 	/* batching */
@@ -694,7 +753,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	auto build_cuckoo = [&]() {
 		/* slots: power of two with load <= 0.4; at least 32 */
 		uint64_t slots = 32;
-		while ((double) n > 0.4 * (double) slots) slots <<= 1;
+		while ((double) n > NTSM_TABLE_LOAD * (double) slots) slots <<= 1;
 		for (;; slots <<= 1) {
 			const uint32_t blog = (uint32_t) __builtin_ctzll(slots >> 1);
 			const uint32_t bshift = 32 - blog;
@@ -797,7 +856,9 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 				blk[2] |= 1u << NTSM_KBIT2(um);
 				blk[3] |= 1u << NTSM_KBIT3(um);
 			}
-			if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0u);   /* ablation only: wrong counts */
+#ifdef NTSM_ABLATION                                              /* tools/ablate*.py builds only: wrong counts */
+			if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0u);
+#endif
 		}
 	};
 	auto build_prefilter = [&]() {
@@ -806,7 +867,9 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		if (c->k == NTSM_FAST_K) {
 			uint32_t pl = 10;
 			while (pl < 28 && (1ull << pl) < 5ull * n) ++pl;
+#ifdef NTSM_ABLATION
 			if (const char *ev = getenv("NTSM_PREFILTER_LOG2")) pl = (uint32_t) atoi(ev);
+#endif
 			if (pl < 10) pl = 10;
 			if (pl > 30) pl = 30;
 			c->prefilter_log2 = pl;
@@ -816,13 +879,51 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 				const uint32_t f = ntsm_fold(c->canon[i]), g1 = ntsm_h1(f), g2 = ntsm_h2(f);
 				prefilter[g1 >> pshift] |= (1u << (g2 & 31u)) | (1u << ((g2 >> 5) & 31u));
 			}
-			if (getenv("NTSM_PREFILTER_OFF")) std::fill(prefilter.begin(), prefilter.end(), 0xFFFFFFFFu);   /* ablation: everything passes */
+#ifdef NTSM_ABLATION
+			if (getenv("NTSM_PREFILTER_OFF")) std::fill(prefilter.begin(), prefilter.end(), 0xFFFFFFFFu);   /* everything passes */
+#endif
 		}
 	};
+	std::vector<uint32_t> tblocks;
+	auto build_tblocks = [&]() {
+		/* k = 19, tabulated kernel: the same kind of filter (128-bit blocks, 4 bits per key, >= 12 bits per key, 3 MiB for
+		 * the human set) addressed and filled with the table-driven hashes of ntsm_device.h */
+		c->tab_ok = false;
+		if (c->k != NTSM_FAST_K) return;
+		NtsmTabEntry tab[256];
+		ntsm_tab_build(tab);
+		uint32_t e = 6, mult = 1;
+		if (filter_log2_req >= 100 && filter_log2_req <= 130) {
+			mult = 3; e = (uint32_t) (filter_log2_req - 100) - 7;
+		} else if (filter_log2_req >= 10 && filter_log2_req <= 30) {
+			e = (uint32_t) filter_log2_req - 7;
+		} else {
+			const uint64_t want = (12ull * n + 127) / 128;
+			while ((1ull << e) < want && e < 24) ++e;
+			if (e > 8 && e - 2 <= 20 && (3ull << (e - 2)) >= want) { mult = 3; e -= 2; }
+		}
+		if (e < 4) e = 4;
+		if (mult == 3 && e > 20) e = 20;
+		if (e > 24) e = 24;
+		c->n_tblocks = (uint64_t) mult << e;
+		c->tblk_map.mult3 = mult == 3;
+		c->tblk_map.mask = ((1u << e) - 1u) << 4;
+		c->tblk_map.shift = mult == 3 ? 20 - e : 0;
+		tblocks.assign(c->n_tblocks * 4, 0u);
+		bool ok = true;
+		for (uint32_t i = 0; i < n; ++i) {
+			uint32_t mz, h;
+			ntsm_tab_kmer(tab, c->canon[i], &mz, &h);
+			if (mz == 0xFFFFFFFFu) ok = false;                    /* the key the kernel reserves for "window invalid" */
+			uint32_t *blk = &tblocks[(size_t) (ntsm_tab_block_off(mz, c->tblk_map) >> 4) * 4];
+			for (int w = 0; w < 4; ++w) blk[w] |= 1u << ntsm_tab_bit(h, w);
+		}
+		c->tab_ok = ok;
+	};
 	{
-		std::thread t1(build_filter), t2(build_blocks), t3(build_prefilter);
+		std::thread t1(build_filter), t2(build_blocks), t3(build_prefilter), t4(build_tblocks);
 		build_cuckoo();
-		t1.join(); t2.join(); t3.join();
+		t1.join(); t2.join(); t3.join(); t4.join();
 	}
 	if (cuckoo_rc) return cuckoo_rc;
 	/* upload */
@@ -837,6 +938,18 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	if (!blocks.empty()) {
 		HIPCHK(hipMalloc(&c->d_blocks, blocks.size() * sizeof(uint32_t)));
 		HIPCHK(hipMemcpy(c->d_blocks, blocks.data(), blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
+	if (c->d_tblocks) (void) hipFree(c->d_tblocks);
+	c->d_tblocks = nullptr;
+	if (!tblocks.empty()) {
+		HIPCHK(hipMalloc(&c->d_tblocks, tblocks.size() * sizeof(uint32_t)));
+		HIPCHK(hipMemcpy(c->d_tblocks, tblocks.data(), tblocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		if (!c->d_tab) {
+			NtsmTabEntry tab[256];
+			ntsm_tab_build(tab);
+			HIPCHK(hipMalloc(&c->d_tab, sizeof tab));
+			HIPCHK(hipMemcpy(c->d_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+		}
 	}
 	if (c->d_filter) (void) hipFree(c->d_filter);
 	if (c->d_keys) (void) hipFree(c->d_keys);
@@ -926,10 +1039,82 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.blocks = c->d_blocks;
 	p.blk_map = c->blk_map;
 	p.prefilter = c->d_prefilter;
-	if (const char *dv = getenv("NTSM_DEBUG_KERNEL")) p.debug = (uint32_t) atoi(dv);
+#ifdef NTSM_ABLATION
+	{
+		static const char *dv = getenv("NTSM_DEBUG_KERNEL");
+		if (dv) p.debug = (uint32_t) atoi(dv);
+	}
+#endif
 	p.pf_shift = 32 - (c->prefilter_log2 - 5);
 	p.blk_bytes = (uint32_t) (c->n_blocks * 16);
 	const bool fast = c->k == NTSM_FAST_K && c->d_blocks && c->kernel_variant != 1;
+	const bool tab = fast && !per_read && c->tab_ok && c->d_tblocks && c->kernel_variant == 3;
+	NtsmCountParams pt = p;                                 /* the tabulated kernel's view: 64 KiB tiles, segments of kTabSegTiles */
+	uint64_t tab_tiles = 0, tab_segs = 0;
+	ntsm_ctx::StreamBuf tab_sb = { nullptr, nullptr, 0, 0, nullptr, 0, { nullptr, nullptr }, { nullptr, nullptr } };
+	if (tab) {
+		tab_tiles = (hi - (uint64_t) p.t0 + (uint64_t) kTabTile - 1) / (uint64_t) kTabTile;
+		tab_segs = (tab_tiles + kTabSegTiles - 1) / kTabSegTiles;
+		pt.tab = c->d_tab;
+		pt.tblocks = c->d_tblocks;
+		pt.tblk_bytes = (uint32_t) (c->n_tblocks * 16);
+		pt.tblk_map = c->tblk_map;
+		const uint64_t need_exotic = 2 * tab_tiles + 2;
+		/* queue: kTabQueue codes per (tile, wave) of the largest segment -- one window in 16; a wave with more positives
+		 * than that looks them up in line */
+		const uint64_t seg_slots = std::min<uint64_t>(tab_tiles, kTabSegTiles) * (uint64_t) (kThreads / 64);
+		const uint64_t need_queue = seg_slots * (uint64_t) kTabQueue;
+		{
+			std::lock_guard<std::mutex> lk(c->mu);
+			ntsm_ctx::StreamBuf *sb = nullptr;
+			for (auto &b : c->sbuf) if (b.stream == st) sb = &b;
+			if (!sb) {
+				ntsm_ctx::StreamBuf nb = { st, nullptr, 0, 0, nullptr, 0, { nullptr, nullptr }, { nullptr, nullptr } };
+				for (int q = 0; q < 2; ++q) {
+					HIPCHK(hipEventCreateWithFlags(&nb.ev_tab[q], hipEventDisableTiming));
+					HIPCHK(hipEventCreateWithFlags(&nb.ev_look[q], hipEventDisableTiming));
+				}
+				c->sbuf.push_back(nb);
+				sb = &c->sbuf.back();
+			}
+			if (!c->lstream && !(c->lstream = stream_get(c->device))) return NTSM_ERR_HIP;
+			if (sb->exotic_cap < need_exotic || sb->seg_cap < seg_slots) {   /* first launch on this stream, or a bigger batch than ever */
+				uint32_t seen = 0;
+				if (sb->d_ctl) {
+					HIPCHK(hipStreamSynchronize(st));
+					HIPCHK(hipMemcpy(&seen, sb->d_ctl + 1 + 2 * sb->seg_cap, sizeof seen, hipMemcpyDeviceToHost));
+					HIPCHK(hipFree(sb->d_ctl));
+					sb->d_ctl = nullptr;
+				}
+				const uint64_t ecap = std::max<uint64_t>(need_exotic, 1024), scap = std::max<uint64_t>(seg_slots, 16);
+				HIPCHK(hipMalloc(&sb->d_ctl, (2 + 2 * scap + ecap) * sizeof(uint32_t)));
+				HIPCHK(hipMemcpy(sb->d_ctl + 1 + 2 * scap, &seen, sizeof seen, hipMemcpyHostToDevice));
+				sb->exotic_cap = ecap;
+				sb->seg_cap = scap;
+			}
+			if (sb->queue_cap < need_queue) {
+				if (sb->d_queue) {
+					HIPCHK(hipStreamSynchronize(st));
+					HIPCHK(hipFree(sb->d_queue));
+					sb->d_queue = nullptr;
+				}
+				HIPCHK(hipMalloc(&sb->d_queue, 2 * need_queue * sizeof(unsigned long long)));
+				sb->queue_cap = need_queue;
+			}
+			pt.exotic_count = sb->d_ctl;
+			pt.pos_count = sb->d_ctl + 1;
+			pt.exotic_seen = sb->d_ctl + 1 + 2 * sb->seg_cap;
+			pt.exotic_list = sb->d_ctl + 2 + 2 * sb->seg_cap;
+			tab_sb = *sb;
+			pt.exotic_cap = (uint32_t) std::min<uint64_t>(sb->exotic_cap, 0xFFFFFFFFu);
+			pt.pos_queue = sb->d_queue;
+			pt.pos_cap = 0;
+		}
+		p.exotic_count = pt.exotic_count;
+		p.exotic_list = pt.exotic_list;
+		p.exotic_cap = pt.exotic_cap;
+		p.use_list = 1;
+	}
 	/* Grid: many more workgroups than fit on the chip at once (4 per CU), each walking ~8+ tiles.  A grid of
 	 * exactly the resident workgroups (static tile assignment) measured 11 % slower: the slowest CU sets the
 	 * finish time; with 32k-128k workgroups the dispatcher balances the load (measured plateau), while fewer
@@ -937,9 +1122,11 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	uint64_t grid = c->grid_blocks > 0 ? (uint64_t) c->grid_blocks : std::min<uint64_t>(65536, std::max<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles / 8));
 	if (grid > p.n_tiles) grid = p.n_tiles;
 	int ev = -1;
-	std::unique_lock<std::mutex> timing_lock(c->mu, std::defer_lock);   /* the event pool is shared by all lanes */
+	/* The event pool is shared by all lanes; and the tabulated path is three enqueues on one stream (reset of the tile
+	 * list, kernel, list walker) that must not interleave with another lane's three on the same stream. */
+	std::unique_lock<std::mutex> timing_lock(c->mu, std::defer_lock);
+	if (c->timing || tab) timing_lock.lock();
 	if (c->timing) {
-		timing_lock.lock();
 		ev = c->ev_next;
 		c->ev_next = (c->ev_next + 1) % kTimingPool;
 		if (c->ev_used[ev]) {                             /* recycle: fold the old measurement in */
@@ -951,14 +1138,50 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		}
 		HIPCHK(hipEventRecord(c->ev_a[ev], st));
 	}
-	if (fast && per_read)
+	if (tab) {
+		/* the tabulated kernel counts every tile whose bytes are all ACGTUNacgtun and lists the others; the exact
+		 * minimizer-blocked kernel then walks that list (usually empty: it exits at once) */
+		HIPCHK(hipMemsetAsync(pt.exotic_count, 0, sizeof(uint32_t), st));   /* fill of the exotic-tile list */
+		for (uint64_t sg = 0; sg < tab_segs; ++sg) {
+			const int hb = (int) (sg & 1);                        /* half of queue + fills this segment uses */
+			NtsmCountParams ps = pt;
+			ps.tile_base = sg * kTabSegTiles;
+			ps.t0 = pt.t0 + (long long) (ps.tile_base * (uint64_t) kTabTile);
+			ps.n_tiles = std::min<uint64_t>(kTabSegTiles, tab_tiles - ps.tile_base);
+			ps.pos_count = pt.pos_count + (uint64_t) hb * tab_sb.seg_cap;
+			ps.pos_queue = pt.pos_queue + (uint64_t) hb * tab_sb.queue_cap;
+			if (sg >= 2) HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[hb], 0));   /* the half's previous look-up has finished */
+			const uint64_t tgrid = c->grid_blocks > 0 ? std::min<uint64_t>((uint64_t) c->grid_blocks, ps.n_tiles) : std::max<uint64_t>(1, ps.n_tiles / NTSM_TAB_TILES_PER_WG);
+			if (ps.tblk_map.mult3) hipLaunchKernelGGL((ntsm_count_tab19_kernel<true>), dim3((unsigned) tgrid), dim3(kThreads), 0, st, ps);
+			else hipLaunchKernelGGL((ntsm_count_tab19_kernel<false>), dim3((unsigned) tgrid), dim3(kThreads), 0, st, ps);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipEventRecord(tab_sb.ev_tab[hb], st));
+			HIPCHK(hipStreamWaitEvent(c->lstream, tab_sb.ev_tab[hb], 0));
+			/* one look-up workgroup per CU: its four waves fit into the registers the scan kernel's three waves per SIMD leave */
+			const uint64_t lgrid = std::min<uint64_t>((uint64_t) NTSM_LOOK_WGS, std::max<uint64_t>(1, ps.n_tiles));
+			hipLaunchKernelGGL(ntsm_lookup_kernel, dim3((unsigned) lgrid), dim3(kThreads), 0, c->lstream, ps);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipEventRecord(tab_sb.ev_look[hb], c->lstream));
+		}
+		/* whatever follows on the launch stream (the list walker, the timing event, the caller's sync) sees the look-ups done */
+		HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[(tab_segs - 1) & 1], 0));
+		if (tab_segs > 1) HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[tab_segs & 1], 0));
+		hipLaunchKernelGGL((ntsm_count_k19_kernel<false>), dim3((unsigned) std::min<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles)), dim3(kThreads), 0, st, p);
+		c->n_launch[0]++;
+	} else if (fast && per_read) {
 		hipLaunchKernelGGL((ntsm_count_k19_kernel<true>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
-	else if (fast)
+		c->n_launch[1]++;
+	} else if (fast) {
 		hipLaunchKernelGGL((ntsm_count_k19_kernel<false>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
-	else if (per_read)
+		c->n_launch[1]++;
+	}
+	else if (per_read) {
 		hipLaunchKernelGGL((ntsm_count_kernel<kTileC, true>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
-	else
+		c->n_launch[2]++;
+	} else {
 		hipLaunchKernelGGL((ntsm_count_kernel<kTileC, false>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
+		c->n_launch[2]++;
+	}
 	HIPCHK(hipGetLastError());
 	if (ev >= 0) {
 		HIPCHK(hipEventRecord(c->ev_b[ev], st));
@@ -1202,7 +1425,16 @@ void ntsm_destroy(ntsm_ctx *c)
 		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
 		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
 	}
-	void *ptrs[] = { c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
+	for (auto &b : c->sbuf) {
+		if (b.d_ctl) (void) hipFree(b.d_ctl);
+		if (b.d_queue) (void) hipFree(b.d_queue);
+		for (int q = 0; q < 2; ++q) {
+			if (b.ev_tab[q]) (void) hipEventDestroy(b.ev_tab[q]);
+			if (b.ev_look[q]) (void) hipEventDestroy(b.ev_look[q]);
+		}
+	}
+	stream_put(c->device, c->lstream);
+	void *ptrs[] = { c->d_tab, c->d_tblocks, c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
 	for (void *p : ptrs) if (p) (void) hipFree(p);
 	delete c;
 }
@@ -1593,10 +1825,33 @@ void *ntsm_stream(ntsm_ctx *c) { return c ? (void *) c->rstream : nullptr; }
 
 int ntsm_set_kernel(ntsm_ctx *c, int variant)
 {
-	if (!c || variant < 0 || variant > 1) return NTSM_ERR_ARG;
+	if (!c || variant < 0 || variant > 3) return NTSM_ERR_ARG;
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
 	c->kernel_variant = variant;
+	return NTSM_OK;
+}
+
+int ntsm_debug_stats(ntsm_ctx *c, uint64_t out[8])
+{
+	if (!c || !out) return NTSM_ERR_ARG;
+	int rc = ntsm_sync(c, nullptr);
+	if (rc) return rc;
+	HIPCHK(hipDeviceSynchronize());
+	uint64_t exotic = 0;
+	for (auto &b : c->sbuf) {
+		uint32_t seen = 0;
+		if (b.d_ctl) HIPCHK(hipMemcpy(&seen, b.d_ctl + 1 + 2 * b.seg_cap, sizeof seen, hipMemcpyDeviceToHost));
+		exotic += seen;
+	}
+	out[0] = exotic;
+	out[1] = c->n_launch[0];
+	out[2] = c->n_launch[1];
+	out[3] = c->n_launch[2];
+	uint64_t dv[4] = { 0, 0, 0, 0 };
+	HIPCHK(hipMemcpy(dv, c->d_totals, sizeof dv, hipMemcpyDeviceToHost));
+	out[4] = dv[2];
+	out[5] = out[6] = out[7] = 0;
 	return NTSM_OK;
 }
 

@@ -140,8 +140,8 @@ def test_random_reads_vs_oracle_n10(nt, n10):
     fp = OracleFP(path)
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)   # one long "read": terminators reset windows
     _, _, ocnt = fp.kmers()
-    # kernel variants (0 = minimizer-blocked fast path, 1 = generic) and filter sizes must all agree
-    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18)):
+    # kernel variants (0 = minimizer-blocked fast path, 1 = generic, 3 = tabulated) and filter sizes must all agree
+    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (3, 0), (3, 20), (3, 25), (3, 124)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         if flog:
@@ -640,15 +640,112 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
         fp.L.ntsm_oracle_fp_insert_count(fp.h, buf.tobytes(), n)
         ends = np.array([n], dtype=np.uint64)
         flat = np.concatenate([buf, np.frombuffer(b"N", dtype=np.uint8)])
-        for variant in (0, 1):
+        for variant in (0, 1) + ((3,) if k == 19 else ()):
             ctx = nt.Context(sites.keys, k=k)
             ctx.set_kernel(variant)
             ctx.submit(flat, ends)
             t = ctx.sync()
             assert np.array_equal(ctx.counts(), fp.kmers()[2]), (k, variant)
             assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, n), (k, variant)
+            if variant == 3:          # the tabulated kernel only takes ACGTUNacgtun: every 64 KiB tile here goes to the exact kernel
+                st = ctx.debug_stats()
+                assert st["launches_tab"] == 1 and st["exotic_tiles"] == -(-(n + 1) // 65536), st
             ctx.close()
         assert fp.total_hits > 100
+
+
+def test_tabulated_kernel_paths(nt, n10, tmp_path):
+    """The tabulated k = 19 kernel (ntsm_set_kernel 3) on the inputs that take its special paths, against the oracle:
+    (a) reads made of site sequence -- far more windows pass the filter than a wave's queue slot holds, so they are looked
+    up in line; (b) a clean stream with a few foreign bytes -- only the tiles that hold them go to the exact kernel;
+    (c) lowercase / U / N-rich input stays on the tabulated kernel; (d) several launches reuse the per-stream buffers."""
+    s, sites, path = n10
+    rng = np.random.default_rng(7)
+    win = s.windows.reshape(-1, 32)[:, :31]
+    # (a) 40k site windows back to back, each followed by 'N'
+    pick = np.frombuffer(b"ACGT", dtype=np.uint8)[win[rng.integers(0, win.shape[0], 40_000)]]   # windows are stored as codes 0..3
+    dense = np.concatenate([pick, np.full((pick.shape[0], 1), ord("N"), np.uint8)], axis=1).reshape(-1)
+    ends = (np.arange(pick.shape[0], dtype=np.uint64) * np.uint64(32)) + np.uint64(31)
+    # (b)+(c) 6000 seeded reads, some lowercase, some T -> U, extra N, and three foreign bytes far apart
+    n = 6000
+    clean = s.host_bytes(0, n).copy()
+    low = rng.random(clean.size) < 0.3
+    clean[low & (clean != ord("N"))] |= 0x20
+    tmask = (clean == ord("T")) & (rng.random(clean.size) < 0.5)
+    clean[tmask] = ord("U")
+    clean[rng.integers(0, clean.size, 200)] = ord("n")
+    for r in range(n):                                   # keep the terminators
+        clean[r * s.stride + s.read_len] = ord("N")
+    foreign = clean.copy()
+    for at, b in ((1000, ord("R")), (70_000, 0), (500_000, ord("-"))):
+        foreign[at] = b
+    cends = s.read_end(n)
+    for name, buf, e, exotic in (("dense", dense, ends, 0), ("clean", clean, cends, 0), ("foreign", foreign, cends, 3)):
+        fp = OracleFP(path)
+        fp.process_flat(buf, e)
+        ctx = nt.Context(sites.keys)
+        ctx.set_kernel(3)
+        for rep in range(2):                             # second launch: buffers reused, counts double
+            ctx.submit(buf, e)
+        t = ctx.sync()
+        st = ctx.debug_stats()
+        assert np.array_equal(ctx.counts(), 2 * fp.kmers()[2]), name
+        assert (t.total_kmers, t.total_hits, t.total_bases) == (2 * fp.total_kmers, 2 * fp.total_hits, 2 * fp.total_bases), name
+        assert st["launches_tab"] == 2 and st["exotic_tiles"] == 2 * exotic, (name, st)
+        if name == "dense":
+            assert fp.total_hits > 0.3 * fp.total_kmers and st["queued_windows"] < fp.total_hits   # most were looked up in line
+        ctx.close()
+
+
+def test_resident_stream_beyond_4gib(nt, n10):
+    """A resident stream of 6e7 reads (9.06 GB: byte offsets far beyond 2^32 inside ONE launch): counts of the whole
+    buffer == the sum over pieces of < 2 GiB counted separately (each piece re-based, so its offsets are small), for the
+    default and the tabulated kernel; and a window cut from beyond byte 2^32 equals the oracle on the same reads."""
+    import torch
+    s, sites, path = n10
+    dev = torch.device("cuda:0")
+    n = 60_000_000
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d = torch.empty(n * s.stride, dtype=torch.uint8, device=dev)
+    s.device_fill(d_win.data_ptr(), 0, n, d.data_ptr())
+    torch.cuda.synchronize()
+    piece = 13_000_000                                   # 1.96 GB
+    ref = nt.Context(sites.keys)
+    for r0 in range(0, n, piece):
+        m = min(piece, n - r0)
+        ref.count_resident(d.data_ptr() + r0 * s.stride, m * s.stride, 0, m)
+    tr = ref.sync()
+    cr = ref.counts()
+    ref.close()
+    assert tr.total_bases == n * s.read_len and tr.total_hits > 1_000_000
+    for variant in (0, 3):
+        ctx = nt.Context(sites.keys)
+        ctx.set_kernel(variant)
+        ctx.count_resident(d.data_ptr(), n * s.stride, 0, n)
+        t = ctx.sync()
+        assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (tr.total_kmers, tr.total_hits, tr.total_bases, n), variant
+        assert np.array_equal(ctx.counts(), cr), variant
+        ctx.close()
+    # oracle on reads [3.5e7, 3.5e7 + 30000): byte offset 5.3e9 of the resident buffer
+    r0, m = 35_000_000, 30_000
+    assert r0 * s.stride > 2 ** 32
+    fp = OracleFP(path)
+    fp.process_flat(s.host_bytes(r0, m), s.read_end(m))
+    ctx = nt.Context(sites.keys)
+    ctx.count_resident(d.data_ptr() + r0 * s.stride, m * s.stride, 0, m)
+    t = ctx.sync()
+    assert np.array_equal(ctx.counts(), fp.kmers()[2])
+    assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
+    # the same window as part of the big launch: whole minus (before + after) == oracle
+    ctx.reset()
+    ctx.count_resident(d.data_ptr(), n * s.stride, 0, n)
+    ctx.count_resident(d.data_ptr(), r0 * s.stride, 0, r0, sign=-1)
+    ctx.count_resident(d.data_ptr() + (r0 + m) * s.stride, (n - r0 - m) * s.stride, 0, n - r0 - m, sign=-1)
+    t = ctx.sync()
+    assert np.array_equal(ctx.counts(), fp.kmers()[2])
+    assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
+    ctx.close()
+    del d
 
 
 def test_cli_reads_from_pipes(nt):
