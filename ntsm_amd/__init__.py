@@ -6,7 +6,7 @@ This package is only the ctypes plumbing tests and bench.py use; importing it fa
 HIP library has not been built (there is no CPU fallback)."""
 from . import capi
 from .capi import (Context, Lane, Sites, SynthLong, SynthShort, flatten_file, hash64, hash64_inv, hip_lib, host_lib,
-                   max_hits_for, synth_lib, warmup, staging_pool, NtsmError)
+                   max_hits_for, synth_lib, warmup, staging_pool, allreduce, NtsmError)
 
 __all__ = ["capi", "Context", "Lane", "warmup", "staging_pool", "Sites", "SynthShort", "SynthLong", "flatten_file", "hash64", "hash64_inv", "hip_lib",
-           "host_lib", "synth_lib", "max_hits_for", "NtsmError"]
+           "host_lib", "synth_lib", "max_hits_for", "allreduce", "NtsmError"]

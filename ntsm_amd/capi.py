@@ -349,6 +349,13 @@ class Lane:
             pass
 
 
+def allreduce(contexts):
+    """ntsm_allreduce: one process, one context per GPU -- RCCL SUM of the count vectors + totals; afterwards every
+    context's counts()/sync() report the job-wide result."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _chk(H.ntsm_allreduce(arr, len(contexts)), "ntsm_allreduce")
+
+
 def warmup(device=0, n_streams=0):
     _chk(H.ntsm_warmup(device, n_streams), "ntsm_warmup")
 

@@ -123,6 +123,14 @@ void Feeder::feedRead(const char *seq, uint64_t len)
 {
 	if (m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)) flush();
 	if (m_earlyTerm) return;
+	if (m_bases && m_nReads == 0 && len + 1 > m_capBytes) {
+		/* an acquired but empty slot (after discard(): flush() has nothing to submit and keeps it) that is too small for
+		 * this read: hand it back empty so that the grow path below runs instead of writing past its end */
+		int rc = m_useLane ? ntsm_lane_submit(m_lane, 0, 0) : ntsm_submit_staged(m_ctx, 0, 0);
+		if (rc) die(rc, "cannot return an empty staging slot");
+		m_bases = nullptr;
+		m_fill = 0;
+	}
 	if (!m_bases) {
 		if (len + 1 > m_cfgBytes) {                              /* a read longer than a slot: grow both slots */
 			m_cfgBytes = (len + 1) + (len + 1) / 2;
@@ -318,22 +326,15 @@ void FingerPrint::fetchResults()
 	closeLanes();
 	m_counts.assign(m_sites.keys.size(), 0);
 	m_totals = ntsm_totals();
-	std::vector<uint64_t> part(m_sites.keys.size());
-	for (ntsm_ctx *c : m_ctx) {
-		ntsm_totals t;
-		int rc = ntsm_sync(c, &t);
-		if (rc == 0) rc = ntsm_counts(c, m_ctx.size() == 1 ? m_counts.data() : part.data());
-		if (rc) {
-			std::cerr << "ntsmCount: cannot fetch counts: " << ntsm_strerror(rc) << std::endl;
-			exit(1);
-		}
-		if (m_ctx.size() > 1)
-			for (size_t i = 0; i < part.size(); ++i) m_counts[i] += part[i];
-		m_totals.total_kmers += t.total_kmers;
-		m_totals.total_hits += t.total_hits;
-		m_totals.total_bases += t.total_bases;
-		m_totals.reads_consumed += t.reads_consumed;
-		m_totals.early_stop |= t.early_stop;
+	/* Several devices (-g a,b,...): one RCCL SUM of the dense per-k-mer vectors + totals over xGMI, after which every
+	 * context reports the job-wide result -- SUM, not MAX: the per-site maxima are taken from the summed counts, which is
+	 * what one reference run over all reads computes (src/FingerPrint.hpp:281-294). */
+	int rc = m_ctx.size() > 1 ? ntsm_allreduce(m_ctx.data(), (int) m_ctx.size()) : NTSM_OK;
+	if (rc == 0) rc = ntsm_sync(m_ctx[0], &m_totals);
+	if (rc == 0) rc = ntsm_counts(m_ctx[0], m_counts.data());
+	if (rc) {
+		std::cerr << "ntsmCount: cannot fetch counts: " << ntsm_strerror(rc) << std::endl;
+		exit(1);
 	}
 	m_fetched = true;
 }

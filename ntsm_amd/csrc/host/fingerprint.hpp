@@ -51,6 +51,8 @@ public:
 	/* Sink interface of the block-parallel ingest (parallel_fastq.hpp) */
 	bool has_room(uint64_t len) const { return !(m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)); }
 	void feed(const char *seq, uint64_t len) { feedRead(seq, len); }
+	/* Drop what is staged.  The slot stays acquired (it is handed back by the next submit), so feedRead() must still
+	 * be able to grow it: it checks the capacity whenever the batch is empty, not only when no slot is held. */
 	void discard() { m_fill = 0; m_nReads = 0; }
 	void begin_block(size_t) { }
 	/* flush + close the lane (its totals fold into the context); the Feeder must not be fed afterwards */

@@ -92,7 +92,7 @@ __device__ __forceinline__ unsigned long long ntsm_read_of(const NtsmCountParams
 }
 
 template <int C, bool PER_READ>
-__global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountParams p)
+__global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(const NtsmCountParams p)
 {
 	constexpr int ROW = C + 16;
 	constexpr int VPT = C / 16;                              /* vectors per thread */
@@ -108,12 +108,26 @@ __global__ __launch_bounds__(kThreads) void ntsm_count_kernel(const NtsmCountPar
 	for (unsigned long long ti = blockIdx.x; ti < p.n_tiles; ti += gridDim.x) {
 		const long long ts = p.t0 + (long long) (ti * (unsigned long long) (kThreads * C));
 		__syncthreads();                                     /* previous tile fully consumed */
+		if (ts >= p.lo && ts + kThreads * C <= p.hi) {           /* interior tile: no boundary logic (~100 VALU instructions per vector) */
 #pragma unroll
-		for (int q = 0; q < VPT; ++q) {
-			const int v = t + kThreads * q;
-			const uint4 r = ntsm_load_vec(p, ts + 16ll * v);
-			const int row = 1 + (16 * v) / C, col = (16 * v) % C;
-			*reinterpret_cast<uint4 *>(tile + row * ROW + col) = r;
+			for (int q = 0; q < VPT; ++q) {
+				const int v = t + kThreads * q;
+#if NTSM_STREAM_NT
+				const u32x4 nt = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p.base + ts + 16ll * v));
+#else
+				const u32x4 nt = *reinterpret_cast<const u32x4 *>(p.base + ts + 16ll * v);
+#endif
+				const int row = 1 + (16 * v) / C, col = (16 * v) % C;
+				*reinterpret_cast<uint4 *>(tile + row * ROW + col) = make_uint4(nt.x, nt.y, nt.z, nt.w);
+			}
+		} else {
+#pragma unroll 1
+			for (int q = 0; q < VPT; ++q) {
+				const int v = t + kThreads * q;
+				const uint4 r = ntsm_load_vec(p, ts + 16ll * v);
+				const int row = 1 + (16 * v) / C, col = (16 * v) % C;
+				*reinterpret_cast<uint4 *>(tile + row * ROW + col) = r;
+			}
 		}
 		if (t < 2) {
 			const uint4 r = ntsm_load_vec(p, ts - 32 + 16 * t);
@@ -240,7 +254,7 @@ __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
 }
 
 template <bool PER_READ>
-__global__ __launch_bounds__(kThreads, NTSM_FAST_WAVES) void ntsm_count_k19_kernel(const NtsmCountParams p)
+__global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_k19_kernel(const NtsmCountParams p)
 {
 	constexpr int C = kFastC, VPT = C / 16, NB = C / 8;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * C];
@@ -1771,6 +1785,7 @@ int ntsm_set_max_hits(ntsm_ctx *c, uint64_t max_hits, int armed)
 	if (rc) return rc;
 	c->max_hits = max_hits;
 	c->armed = armed != 0;
+	c->reduced = false;                                    /* what follows is counted locally: ntsm_sync reports this context's own totals again */
 	return NTSM_OK;
 }
 
@@ -1892,20 +1907,33 @@ int ntsm_allreduce(ntsm_ctx *const *ctxs, int n)
 		static Rccl rccl;                                     /* thread-safe one-time binding */
 		if (!rccl.ok) return NTSM_ERR_RCCL;
 		std::vector<int> devs(n);
-		std::vector<ncclComm_t> comms(n);
 		for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
-		if (rccl.CommInitAll(comms.data(), n, devs.data()) != ncclSuccess) return NTSM_ERR_RCCL;
+		for (int i = 0; i < n; ++i)
+			for (int j = 0; j < i; ++j)
+				if (devs[i] == devs[j]) return NTSM_ERR_ARG;    /* one context per device */
+		/* Communicators are kept per device list for the life of the process: ncclCommInitAll costs far more than the
+		 * 12 MB reduction it serves (tens of milliseconds against well under one). */
+		static std::mutex comm_mu;
+		static std::vector<std::pair<std::vector<int>, std::vector<ncclComm_t>>> comm_cache;
+		std::lock_guard<std::mutex> comm_lock(comm_mu);
+		std::vector<ncclComm_t> *comms = nullptr;
+		for (auto &e : comm_cache) if (e.first == devs) comms = &e.second;
+		if (!comms) {
+			std::vector<ncclComm_t> made(n);
+			if (rccl.CommInitAll(made.data(), n, devs.data()) != ncclSuccess) return NTSM_ERR_RCCL;
+			comm_cache.emplace_back(devs, made);
+			comms = &comm_cache.back().second;
+		}
 		bool ok = rccl.GroupStart() == ncclSuccess;
 		for (int i = 0; i < n && ok; ++i) {
 			ok = hipSetDevice(devs[i]) == hipSuccess &&
 				rccl.AllReduce(ctxs[i]->d_vec, ctxs[i]->d_vec, (size_t) ctxs[i]->n_kmers + 4, ncclUint64, ncclSum,
-						comms[i], ctxs[i]->rstream) == ncclSuccess;
+						(*comms)[i], ctxs[i]->rstream) == ncclSuccess;
 		}
 		ok = (rccl.GroupEnd() == ncclSuccess) && ok;
 		for (int i = 0; i < n; ++i) {
 			(void) hipSetDevice(devs[i]);
-			(void) hipStreamSynchronize(ctxs[i]->rstream);
-			rccl.CommDestroy(comms[i]);
+			if (hipStreamSynchronize(ctxs[i]->rstream) != hipSuccess) ok = false;
 		}
 		if (!ok) return NTSM_ERR_RCCL;
 	}

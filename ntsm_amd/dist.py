@@ -74,8 +74,8 @@ class ContextEngine:
 
     def count(self, shard):
         ptr, n_bytes, ends, n_reads = shard
+        self.ctx.set_max_hits(0, armed=False)            # also drops a merged (job-wide) view: totals are this context's own again
         before = self.ctx.sync().total_hits
-        self.ctx.set_max_hits(0, armed=False)
         self.ctx.count_resident(ptr, n_bytes, ends, n_reads, 1)
         return self.ctx.sync().total_hits - before
 

@@ -318,6 +318,34 @@ def test_long_reads_and_m_threshold(nt, n10, tmp_path):
     assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases)
     assert np.array_equal(ctx.counts(), fp.kmers()[2])
     ctx.close()
+    # down-scaled copy of configs[2] itself (tools/config_runs.py long: spacing 16000, -m stop at ~43 % of the stream;
+    # SURVEY.md 8d): 12,000 reads of the same generator, threshold at 43 % of their hits -- the stop index, totals and
+    # counts of the chunked armed path equal the oracle's
+    L2 = nt.SynthLong(s, read_seed=13, spacing=16000)
+    n2 = 12_000
+    ends2, total2 = L2.layout(0, n2)
+    b2, e2 = L2.host_bytes(0, n2)
+    assert np.array_equal(e2, ends2) and b2.size == total2
+    d_e2 = torch.from_numpy(ends2.view(np.int64)).to(dev)
+    d_b2 = torch.empty(total2, dtype=torch.uint8, device=dev)
+    L2.device_fill(d_win.data_ptr(), 0, n2, d_e2.data_ptr(), total2, d_b2.data_ptr())
+    torch.cuda.synchronize()
+    probe = nt.Context(sites.keys)
+    probe.count_resident(d_b2.data_ptr(), total2, d_e2.data_ptr(), n2)
+    thr2 = int(0.43 * probe.sync().total_hits)
+    probe.close()
+    fp2 = OracleFP(path, cov=2.0 * (thr2 + 0.5) / len(sites.keys))
+    assert fp2.max_hits == thr2
+    fp2.process_flat(b2, e2)
+    assert fp2.early_term and 0.3 * n2 < fp2.reads_processed < 0.6 * n2
+    ctx = nt.Context(sites.keys, max_hits=thr2)
+    ctx.count_resident(d_b2.data_ptr(), total2, d_e2.data_ptr(), n2)
+    t = ctx.sync()
+    assert t.early_stop == 1 and t.reads_consumed == fp2.reads_processed
+    assert (t.total_kmers, t.total_hits, t.total_bases) == (fp2.total_kmers, fp2.total_hits, fp2.total_bases)
+    assert np.array_equal(ctx.counts(), fp2.kmers()[2])
+    ctx.close()
+    del d_b2
     # the CLI against the oracle CLI on the same FASTQ (gzip), -m given as on the command line
     fq = str(tmp_path / "long.fq.gz")
     L.write_fastq(fq, 0, 300)
@@ -331,22 +359,27 @@ def test_long_reads_and_m_threshold(nt, n10, tmp_path):
 
 
 def test_large_site_set_regime(nt, tmp_path):
-    """BASELINE.json configs[4] regime at reduced size: 300k sites (4.8 M k-mers, 64 MiB key table, 8 MiB blocked
-    filter: beyond L2) -- counts and totals still equal the oracle's."""
-    s = nt.SynthShort(sites_seed=77, n_sites=300_000, read_seed=3, p_embed=0.3, sites_path=str(tmp_path / "big.fa"))
-    sites = nt.Sites(str(tmp_path / "big.fa"))
-    assert len(sites.keys) == s.n_kmers > 4_000_000
-    n = 150_000
+    """BASELINE.json configs[4] at its stated size: 1,000,000 sites (16 M k-mers, 512 MiB key table, 24 MiB blocked
+    filter: far beyond the 4 MiB L2) -- counts and totals of 120k reads equal the oracle's for every kernel, and with a
+    first-level filter squeezed back into L2 (3 MiB: 1.5 bits per key, nearly everything passes it)."""
+    s = nt.SynthShort(sites_seed=424242, n_sites=1_000_000, read_seed=9, p_embed=0.3, sites_path=str(tmp_path / "stress.fa"))
+    sites = nt.Sites(str(tmp_path / "stress.fa"))
+    assert len(sites.keys) == s.n_kmers > 15_000_000 and sites.n_sites == 1_000_000
+    n = 120_000
     bases, ends = s.host_bytes(0, n), s.read_end(n)
-    fp = OracleFP(str(tmp_path / "big.fa"))
+    fp = OracleFP(str(tmp_path / "stress.fa"))
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)
-    for variant in (0, 1):
+    want = fp.kmers()[2]
+    assert fp.total_hits > 100_000
+    for variant, flog in ((0, 0), (1, 0), (3, 0), (0, 123), (3, 123)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
+        if flog:
+            ctx.set_tuning(flog, 0)
         ctx.submit(bases, ends)
         t = ctx.sync()
-        assert np.array_equal(ctx.counts(), fp.kmers()[2])
-        assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
+        assert np.array_equal(ctx.counts(), want), (variant, flog)
+        assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits), (variant, flog)
         ctx.close()
 
 
@@ -380,6 +413,145 @@ def test_merge_counts_single_rank_roundtrip(nt, n10):
     ctx.submit(s.host_bytes(0, 10), s.read_end(10))      # new local work invalidates the merged view
     assert ctx.sync().reads_consumed == n + 10
     ctx.close()
+
+
+def test_merge_then_step_reports_local_hits(nt, n10):
+    """ContextEngine.count() right after a merge (ntsm_import_reduced leaves the job-wide totals in place): the hits it
+    reports for the next shard are the shard's own, not `local total - merged total`."""
+    import torch
+    from ntsm_amd.dist import ContextEngine, merge_counts
+    s, sites, path = n10
+    dev = torch.device("cuda:0")
+    n = 64_000
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d = torch.empty(n * s.stride, dtype=torch.uint8, device=dev)
+    s.device_fill(d_win.data_ptr(), 0, n, d.data_ptr())
+    ends = torch.from_numpy(s.read_end(n // 2).view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    half = (n // 2) * s.stride
+    ctx = nt.Context(sites.keys)
+    eng = ContextEngine(ctx)
+    h1 = eng.count((d.data_ptr(), half, ends.data_ptr(), n // 2))
+    ptr, words = ctx.counts_device()                      # a merge in which this rank's vector was one of two equal ones
+    from ntsm_amd.dist import _DeviceVector
+    vec = torch.as_tensor(_DeviceVector(ptr, words), device="cuda")
+    vec *= 2
+    torch.cuda.synchronize()
+    ctx.import_reduced()
+    assert ctx.sync().total_hits == 2 * h1
+    h2 = eng.count((d.data_ptr() + half, half, ends.data_ptr(), n // 2))
+    fp = OracleFP(path)
+    fp.process_flat(s.host_bytes(n // 2, n // 2), s.read_end(n // 2))
+    assert h1 > 0 and h2 == fp.total_hits
+    ctx.close()
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+needs_two_gpus = pytest.mark.skipif("_n_gpus() < 2", reason="needs two GPUs on the node (lights up by itself on a multi-GPU box)")
+
+
+@needs_two_gpus
+def test_two_devices_allreduce_cli_and_ordered_stop(nt, n10, tmp_path):
+    """On a node with >= 2 GPUs: (a) one process, two contexts on devices 0 and 1, each counting half of the reads,
+    ntsm_allreduce (RCCL SUM over xGMI, communicators cached) -> both report the oracle's job-wide counts, twice in a row;
+    (b) `ntsmCount -g 0,1 -t 2` prints the bytes of `-g 0`; (c) OrderedEarlyStop over the two devices == the oracle."""
+    import threading
+    import torch
+    from ntsm_amd.dist import ContextEngine, OrderedEarlyStop
+    s, sites, path = n10
+    n = 200_000
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(path)
+    fp.process_flat(bases, ends)
+    half = (n // 2) * s.stride
+    ctxs = [nt.Context(sites.keys, device=d) for d in (0, 1)]
+    for rep in (1, 2):
+        ctxs[0].submit(bases[:half], ends[:n // 2])
+        ctxs[1].submit(bases[half:], ends[n // 2:] - np.uint64(half))
+        nt.allreduce(ctxs)
+        for c in ctxs:
+            t = c.sync()
+            assert np.array_equal(c.counts(), rep * fp.kmers()[2])
+            assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (rep * fp.total_kmers, rep * fp.total_hits, rep * fp.total_bases, rep * n)
+        for c in ctxs:                                   # drop the merged view: the next round adds to the LOCAL counts again
+            c.set_max_hits(0, armed=False)
+        if rep == 1:                                     # local counts after round 1 are each context's own half
+            assert sum(c.sync().total_hits for c in ctxs) == fp.total_hits
+    [c.close() for c in ctxs]
+    # (b) CLI
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    f1, f2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+    s.write_fastq(f1, 0, 60_000)
+    s.write_fastq(f2, 60_000, 60_000)
+    base = subprocess.run([exe, "-s", path, "-g", "0", f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    two = subprocess.run([exe, "-s", path, "-g", "0,1", "-t", "2", f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert base.returncode == 0 and two.returncode == 0, two.stderr[-400:]
+    assert two.stdout == base.stdout and _summary(two.stderr) == _summary(base.stderr)
+    # (c) ordered -m stop, rank r on device r
+    world, per_super, m = 2, 64_000, 256_000
+    thr = int(0.4 * fp.total_hits * m / n)
+    fpm = OracleFP(path, cov=2.0 * (thr + 0.5) / len(sites.keys))
+    fpm.process_flat(s.host_bytes(0, m), s.read_end(m))
+    assert fpm.early_term
+    devs = [torch.device("cuda", r) for r in range(world)]
+    bufs = []
+    for r in range(world):
+        with torch.cuda.device(devs[r]):
+            w = torch.from_numpy(s.windows).to(devs[r])
+            b = torch.empty(m * s.stride, dtype=torch.uint8, device=devs[r])
+            s.device_fill(w.data_ptr(), 0, m, b.data_ptr())
+            e = torch.from_numpy(s.read_end(per_super // world).view(np.int64)).to(devs[r])
+            torch.cuda.synchronize(devs[r])
+            bufs.append((b, e, w))
+    ctxs = [nt.Context(sites.keys, device=r) for r in range(world)]
+    barrier, box, stops, errs = threading.Barrier(world), [0] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            def all_gather(v):
+                box[rank] = v
+                barrier.wait()
+                out = list(box)
+                barrier.wait()
+                return out
+            st = OrderedEarlyStop(ContextEngine(ctxs[rank]), thr, rank=rank, all_gather=all_gather)
+            stops[rank] = st
+            nr = per_super // world
+            for s0 in range(0, m, per_super):
+                shard = (bufs[rank][0].data_ptr() + (s0 + rank * nr) * s.stride, nr * s.stride, bufs[rank][1].data_ptr(), nr)
+                if st.step(shard, nr):
+                    break
+        except Exception as e:                            # pragma: no cover
+            errs.append(e)
+            barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    nt.allreduce(ctxs)
+    t = ctxs[0].sync()
+    assert sum(st.reads_consumed for st in stops) == fpm.reads_processed == t.reads_consumed
+    assert (t.total_kmers, t.total_hits, t.total_bases) == (fpm.total_kmers, fpm.total_hits, fpm.total_bases)
+    assert np.array_equal(ctxs[1].counts(), fpm.kmers()[2])
+    [c.close() for c in ctxs]
+
+
+@needs_two_gpus
+def test_bench_two_ranks_over_rccl(nt):
+    """bench.py under torch.distributed.run with two ranks (one per GPU, RCCL): the contract line reports n_gpus = 2 and
+    the merged totals of both shards."""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--reads", "2e6", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert "RCCL SUM" in line["config"]["parallelism"]
 
 
 def test_early_stop_across_chunks(nt, n10):
@@ -616,6 +788,20 @@ def test_cli_block_parallel_single_file(nt, tmp_path):
             assert p.stdout == base.stdout
             assert _summary(p.stderr) == _summary(base.stderr)
             assert b"block-parallel" in p.stderr
+    # after a parallel phase that stopped early a thread's staging slot is held but empty; the next file brings a read
+    # larger than the slot (a multi-MB contig): the slot must grow, not overflow (small slots make it certain)
+    rng = np.random.default_rng(5)
+    contig = str(tmp_path / "contig.fa")
+    with open(contig, "wb") as f:
+        f.write(b">c1\n" + bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3_000_000)]) + b"\n")
+    files = [wrapped, contig, fq]
+    base = subprocess.run([exe, "-s", sites_fa] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert base.returncode == 0, base.stderr[-400:]
+    for t, blk, batch in (("4", "65536", "262144"), ("2", "300000", "1048576")):
+        env = dict(os.environ, NTSM_BLOCK_BYTES=blk, NTSM_BATCH_BYTES=batch)
+        p = subprocess.run([exe, "-s", sites_fa, "-t", t] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, p.stderr[-400:]
+        assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr)
 
 
 def test_fuzz_arbitrary_bytes(nt, tmp_path):

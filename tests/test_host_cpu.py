@@ -251,6 +251,25 @@ def test_block_parallel_fastq_ingest(nt, tmp_path):
             assert r[2]["parallel_records"] == 0 and r[2]["resume"] == 0
         if name == "wrapped.fq":
             assert r[2]["parallel_records"] == 10000
+    # the LAST record is not strict and is the first record start of the final block(s): no newline at the end of the file,
+    # wrapped, CRLF -- the parallel phase must stop there (resume < size) and the sequential reader must deliver it
+    head = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGTTGCA" * 12, b"I" * 96) for i in range(59))      # 59 strict records
+    tails = {"tail_noeol.fq": b"@last\n" + b"ACGT" * 25 + b"\n+\n" + b"I" * 100,
+             "tail_wrapped.fq": b"@last\n" + b"ACGT" * 12 + b"\n" + b"ACGT" * 13 + b"\n+\n" + b"I" * 48 + b"\n" + b"I" * 52 + b"\n",
+             "tail_crlf.fq": b"@last\r\n" + b"ACGT" * 25 + b"\r\n+\r\n" + b"I" * 100 + b"\r\n",
+             "tail_long.fq": b"@last\n" + b"ACGT" * 5000 + b"\n+\n" + b"I" * 20000}                     # spans several blocks, no newline at EOF
+    for name, tail in tails.items():
+        for pad in range(0, 4096, 509):                          # slide the last record across the block boundary
+            data = head + b"".join(b"@p%d\n%s\n+\n%s\n" % (i, b"A" * 60, b"I" * 60) for i in range(pad // 127)) + tail
+            pth = str(tmp_path / name)
+            open(pth, "wb").write(data)
+            ref_b, ref_e, ref_rc = nt.flatten_file(pth)
+            for threads, block in ((4, 4096), (3, 8192)):
+                r = flatten_file_parallel(pth, threads, block)
+                if r is None:
+                    continue
+                assert np.array_equal(r[0], ref_b) and np.array_equal(r[1], ref_e), (name, pad, threads, block)
+                assert r[2]["resume"] < len(data), (name, pad)
     # not eligible at all: gzip, FASTA, junk before the first header, small files
     bad = {"junk.fq": b"junk\n" + raw, "tiny.fq": raw[:50_000].rsplit(b"\n@", 1)[0] + b"\n",
            "fasta.fa": b"\n".join(b">" + lines[i][1:] + b"\n" + lines[i + 1] for i in range(0, len(lines) - 1, 4)) + b"\n"}

@@ -74,3 +74,23 @@ if "stress" in which:
                           "reads": n_reads, "kernel_ms": kms, "gbases_per_s": n_reads * 150 / (kms / 1e3) / 1e9,
                           "hits_per_pass": t.total_hits // 2, "site_gen_s": t_gen, "site_load_s": t_load, "create_s": t_create}))
     ctx.close()
+
+if "stress1" in which:                                   # one filter size per process: what tools/stress_profile.sh profiles
+    sp = os.path.join(tmp, "stress.fa")
+    n_sites = int(float(os.environ.get("NTSM_STRESS_SITES", 1e6)))
+    s = ntsm_amd.SynthShort(424242, n_sites, read_seed=9, sites_path=sp)
+    sites = ntsm_amd.Sites(sp)
+    ctx = ntsm_amd.Context(sites.keys)
+    flog = int(os.environ.get("NTSM_STRESS_FLOG", 0))
+    if flog:
+        ctx.set_tuning(flog, 0)
+    if os.environ.get("NTSM_STRESS_KERNEL"):
+        ctx.set_kernel(int(os.environ["NTSM_STRESS_KERNEL"]))
+    n_reads = int(float(os.environ.get("NTSM_STRESS_READS", 1e8)))
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d_bases = torch.empty(n_reads * s.stride, dtype=torch.uint8, device=dev)
+    s.device_fill(d_win.data_ptr(), 0, n_reads, d_bases.data_ptr()); torch.cuda.synchronize()
+    t, dt, kms = timed_pass(ctx, d_bases, d_bases.numel(), None, n_reads, reps=2)
+    print(json.dumps({"config": "configs[4] stress: %d sites, %d k-mers" % (n_sites, len(sites.keys)), "filter_log2": flog or "auto",
+                      "reads": n_reads, "kernel_ms": kms, "gbases_per_s": n_reads * 150 / (kms / 1e3) / 1e9, "hits_per_pass": t.total_hits // 2}))
+    ctx.close()
