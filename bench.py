@@ -21,6 +21,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_FILE = "r02_traffic.json"   # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 SITES_SEED, N_SITES, READ_SEED, READ_LEN, K = 20241218, 96287, 7, 150, 19
 
@@ -175,11 +176,22 @@ def main():
         launch_s = kernel_ms / 1e3 / max(n_launch, 1)
         bytes_per_base = (READ_LEN + 8) / READ_LEN
         achieved = bases_per_step * bytes_per_base / launch_s / 1e9
-        traffic = valu_busy = None              # PMC-derived (separate rocprofv3 --pmc passes, profiles/): bytes per launch, VALU share
+        # PMC-derived constants (separate rocprofv3 --pmc passes, tools/profile.sh + tools/make_traffic.py): bytes per launch,
+        # VALU share, L2 request rate.  They are tied to the kernel sources they were measured on: after any change to those
+        # files they are reported as null until the profile has been taken again.
+        traffic = valu_busy = l2_frac = None
+        traffic_note = "null: no PMC profile of the current kernel sources under profiles/"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            traffic = tj["traffic_bytes_per_base"] * bases_per_step
-            valu_busy = tj.get("valu_busy_frac")
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from make_traffic import kernel_source_sha16
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+            if tj.get("kernel_source_sha16") == kernel_source_sha16() and args.kernel in (0, 2):
+                traffic = tj["traffic_bytes_per_base"] * bases_per_step
+                valu_busy, l2_frac = tj.get("valu_busy_frac"), tj.get("l2_request_rate_frac_of_cap")
+                traffic_note = ("fabric-side bytes/launch from FETCH_SIZE+WRITE_SIZE (profiles/%s): L2 misses of filter/table "
+                                "served by the Infinity Cache + the stream; not HBM re-reads" % TRAFFIC_FILE)
+            else:
+                traffic_note = "null: profiles/%s was measured on other kernel sources (or another kernel variant)" % TRAFFIC_FILE
         except Exception:
             pass
         out = {
@@ -197,13 +209,13 @@ def main():
                                       else "one GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "fabric-side bytes/launch from FETCH_SIZE+WRITE_SIZE (profiles/r01_traffic.json): L2 misses "
-                                         "of filter/table served by the Infinity Cache + the stream; not HBM re-reads",
+                         "traffic_note": traffic_note,
                          "achieved_stream_only_GBs": bases_per_step * (READ_LEN + 1) / READ_LEN / launch_s / 1e9,
                          "kernel": {0: "ntsm_count_k19_kernel", 2: "ntsm_count_k19_kernel", 3: "ntsm_count_tab19_kernel"}.get(args.kernel, "ntsm_count_kernel"),
                          "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
                          "algorithmic_bytes_per_base": bytes_per_base,
-                         "valu_busy_frac_from_pmc": valu_busy,     # the resource that actually binds: share of SIMD issue cycles on VALU
+                         "valu_busy_frac_from_pmc": valu_busy,     # share of SIMD issue cycles on VALU
+                         "l2_request_rate_frac_of_cap_from_pmc": l2_frac,   # the resource that binds: L2 requests/s over the measured 266 G/s cap
                          "kmer_probe_rate_per_s": totals.total_kmers / max(args.steps + args.warmup, 1) / launch_s},
             "check": {"total_kmers_per_step": totals.total_kmers // (args.steps + args.warmup) if world == 1 else None,
                       "total_hits_per_step": totals.total_hits // (args.steps + args.warmup) if world == 1 else None,

@@ -49,29 +49,33 @@ NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC
 #define NTSM_FAST_W (NTSM_FAST_K - NTSM_FAST_M + 1)
 #define NTSM_MMER_MASK ((1u << (2 * NTSM_FAST_M)) - 1u)
 
-/* order hash of a canonical 12-mer (24 bits): injective scramble, compared as an integer */
-NTSM_DHD uint32_t ntsm_mmer_hash(uint32_t cm)
+/* Order hash of a 12-mer: its canonical code (the smaller of the 24-bit forward and reverse-complement codes) times an
+ * odd constant, low 32 bits of the 48-bit product (v_mul_u32_u24), compared as an integer.  Cheaper strand-symmetric
+ * combiners were measured and lose (tools/sim_mmer_order.cpp, tools/filter_fp.cpp on the hs_n10_like set):
+ *   fw + rc, fw ^ rc   depend only on the six differences of mirrored bases: 117,649 values, 3/4 of the filter blocks
+ *                      stay empty, first-level pass rate 63 %;
+ *   fw * rc            two instructions fewer, but minimizer density 0.229 instead of 0.225 and pass rate 1.29 %
+ *                      instead of 1.09 %: 831 instead of 845 Gbases/s -- the kernel is bound by L2 requests, not VALU. */
+NTSM_DHD uint32_t ntsm_mmer_hash(uint32_t canon)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return (uint32_t) __umul24(cm, 0x9E3779u);
+	return (uint32_t) __umul24(canon, 0x9E3779u);       /* __umul24 is declared int in HIP */
 #else
-	return (uint32_t) ((uint64_t) cm * 0x9E3779u);
+	return (uint32_t) ((uint64_t) (canon & 0xFFFFFFu) * 0x9E3779u);
 #endif
 }
-/* BYTE offset of the filter block of a minimizer value.  The filter has n_blocks = mult * 2^e blocks with
- * mult in {1, 3} (3: sizes like 3 MiB that leave room in the 4 MiB per-XCD L2 for the read stream), so the
- * index is a multiply-shift range reduction: h = 24x24-bit multiply (full rate on CDNA) of the low 24 bits of
- * the order hash -- a bijective image of the 12-mer that the min-selection leaves unbiased --, q = its top
- * (e + slack) bits, index = (q * mult) >> slack. */
-struct NtsmBlockMap { uint32_t qshift, mult, sshift; };      /* q = h >> qshift; off = ((q * mult) >> sshift) & ~15 */
-NTSM_DHD uint32_t ntsm_block_off(uint32_t mz, NtsmBlockMap m)
+/* Index of the 128-bit filter block of a minimizer value: h = mz * odd constant (full 32-bit multiply: the top bits of
+ * a minimum are small; the multiply carries every bit of it into the top bits), then the multiply-high range reduction of h onto n_blocks, power of two or
+ * not.  Two instructions (v_mul_lo_u32, v_mul_hi_u32); the kernel hands the index to a buffer load whose descriptor
+ * has a 16-byte stride (idxen), so the byte offset costs nothing. */
+struct NtsmBlockMap { uint32_t n_blocks; };
+NTSM_DHD uint32_t ntsm_block_idx(uint32_t mz, NtsmBlockMap m)
 {
+	const uint32_t h = mz * 0x9E3779B1u;
 #if defined(__HIP_DEVICE_COMPILE__)
-	const uint32_t h = (uint32_t) __umul24(mz, 0xC2B2AFu);      /* __umul24 is declared int in HIP */
-	return ((uint32_t) __umul24(h >> m.qshift, m.mult) >> m.sshift) & ~15u;
+	return __umulhi(h, m.n_blocks);
 #else
-	const uint32_t h = (uint32_t) ((uint64_t) (mz & 0xFFFFFFu) * 0xC2B2AFu);
-	return ((uint32_t) ((uint64_t) (h >> m.qshift) * m.mult) >> m.sshift) & ~15u;
+	return (uint32_t) (((uint64_t) h * m.n_blocks) >> 32);
 #endif
 }
 /* Four filter bits per site k-mer, one in each 32-bit word of its 128-bit block.  u = fh + rh where fh / rh are the
@@ -83,12 +87,12 @@ NTSM_DHD uint32_t ntsm_block_off(uint32_t mz, NtsmBlockMap m)
  * favour the same m-mers, so the blocks that queries hit are the loaded ones and wide blocks pay off. */
 NTSM_DHD uint32_t ntsm_kmer_sum(uint32_t fh, uint32_t rh) { return fh + rh; }
 NTSM_DHD uint32_t ntsm_kmer_mix(uint32_t u) { return u * 0x9E3779B1u; }
-#define NTSM_KBIT0(u) (((u) >> 24) & 31u)
-#define NTSM_KBIT1(um) (((um) >> 24) & 31u)
-#define NTSM_KBIT2(um) (((um) >> 16) & 31u)
-#define NTSM_KBIT3(um) (((um) >> 8) & 31u)
-/* a minimizer value that no 12-mer produces (0x9E3779 * 2^24 mod 2^32): "no block cached yet" */
-#define NTSM_NO_MINIMIZER 0x79000000u
+/* bit index = 31 - field: the kernel shifts the word LEFT by the field (a byte select, the hardware takes its low five
+ * bits) and reads the sign bit, so the four tests and the validity of the window AND together without a final mask */
+#define NTSM_KBIT0(u) (31u - (((u) >> 24) & 31u))
+#define NTSM_KBIT1(um) (31u - (((um) >> 24) & 31u))
+#define NTSM_KBIT2(um) (31u - (((um) >> 16) & 31u))
+#define NTSM_KBIT3(um) (31u - (((um) >> 8) & 31u))
 
 
 /* ---- k = 19 tabulated path ("tab" kernel) ------------------------------------

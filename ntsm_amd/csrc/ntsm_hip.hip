@@ -38,6 +38,13 @@
  * Device code
  * ========================================================================================== */
 
+typedef uint32_t ntsm_u32x4 __attribute__((ext_vector_type(4)));
+typedef int ntsm_i32x4 __attribute__((ext_vector_type(4)));
+/* buffer_load_dwordx4 ... idxen: clang has a builtin for the raw (byte offset) form only, so the LLVM intrinsic is
+ * declared by name.  (descriptor, index, byte offset inside the element, scalar offset, cache policy) */
+__device__ ntsm_u32x4 ntsm_struct_buffer_load_b128(ntsm_i32x4 rsrc, int vindex, int voffset, int soffset, int aux)
+		__asm("llvm.amdgcn.struct.buffer.load.v4i32");
+
 namespace {
 
 #ifndef NTSM_STREAM_NT
@@ -268,10 +275,12 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 	lut64[t] = p.lut64[t];
 	const uint32_t bshift = p.bshift;
 	const NtsmBlockMap blk_map = p.blk_map;
-	/* buffer resource over the filter blocks: one instruction per load, 32-bit byte offset */
-	const __amdgpu_buffer_rsrc_t blk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-			const_cast<uint4 *>(p.blocks), 0, (int) p.blk_bytes, 0x00020000);
-	uint32_t nk = 0, nh = 0;
+	/* Buffer resource over the filter blocks, 16-byte stride: the load takes a block INDEX (idxen), the address
+	 * arithmetic and the range check (index >= number of blocks: returns 0, no memory request) are the hardware's. */
+	const unsigned long long blk_base = (unsigned long long) p.blocks;
+	const ntsm_i32x4 blk_rsrc = { (int) (uint32_t) blk_base, (int) ((uint32_t) (blk_base >> 32) | (16u << 16)),
+			(int) (p.blk_bytes >> 4), 0x00020000 };
+	uint32_t nk_s = 0, nh = 0;                           /* nk_s: wave-uniform (scalar) count of valid windows */
 
 	/* list mode: only the tiles the tabulated kernel handed over (tiles with bytes outside ACGTUNacgtun) */
 	const unsigned long long n_iter = p.use_list ? (unsigned long long) min(*p.exotic_count, p.exotic_cap) : p.n_tiles;
@@ -308,10 +317,12 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		__syncthreads();
 
 		/* Rolling state: F = 2-bit codes of the last 16 bases (newest lowest), R = reverse complement
-		 * of the last 16 bases (complement of the newest base on top), inv = shift register of
-		 * "invalid base" flags.  One op each per base; the 19-mer's two strands are covered by
-		 * F three positions ago (its first 16 bases) and the current R (its last 16, reversed). */
-		uint32_t F = 0, R = 0, inv = 0xFFFFFFFFu;
+		 * of the last 16 bases (complement of the newest base on top), run = 1 + number of valid bases
+		 * since the last invalid one (run * valid + 1: the table's second word carries the complement code
+		 * in its low bits and valid (0/1) in its high half, v_mad_u32_u16 takes that half).  One op each
+		 * per base; the 19-mer's two strands are covered by F three positions ago (its first 16 bases) and
+		 * the current R (its last 16, reversed); the window is valid when run > 19. */
+		uint32_t F = 0, R = 0, run = 1;
 		uint32_t sprev[8];                                  /* suffix minima of the previous 8-block, [1..7] used */
 		uint32_t fc0, fc1, fc2;                             /* F at the three positions before the current block */
 		uint32_t qn = 0;                                    /* wave-uniform queue fill */
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		{                                                                                 \
 			NTSM_F_UPDATE((e_).x)                                                         \
 			R = __builtin_amdgcn_alignbit((e_).y, R, 2);                                  \
-			inv = __builtin_amdgcn_alignbit(inv, (e_).y, 31);                             \
+			asm("v_mad_u32_u16 %0, %1, %2, 1 op_sel:[0,1,0,0]" : "=v"(run) : "v"(run), "v"((e_).y)); \
 		}
 #define NTSM_MMER_G() ntsm_mmer_hash(min(F & NTSM_MMER_MASK, R >> (32 - 2 * NTSM_FAST_M)))
 		{   /* warm-up: the 18 bytes in front of the chunk; 12-mer hashes of positions -7..-1 */
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		}
 		uint32_t mz_prev = 0;
 		uint4 cur = make_uint4(0, 0, 0, 0);                  /* the lane's cached 128-bit filter block */
-		bool ok_prev = false;                               /* nothing cached at the start of a chunk */
+		unsigned long long bad_prev = ~0ull;                /* nothing cached at the start of a chunk */
 
 		/* Drain: look up queued positives 64 at a time, as a three-stage pipeline spread over consecutive
 		 * calls so that no load is consumed in the call that issued it (the wave goes back to the main
@@ -397,11 +408,15 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				s1_v = s1_v && !(p.debug & 1u);
 #endif
 				if (s1_v) {
-					/* rebuild both 38-bit strands from the two 16-base words: the forward code is the first 16
-					 * bases followed by the last 3 (complement-reversed top 3 groups of the reverse word), the
-					 * reverse-complement code is the reverse word followed by the complement-reversed first 3 */
+					/* Rebuild the window from the tile bytes still in LDS (19 byte reads + table reads per 64 positives:
+					 * 0.05 instructions per stream position at the filter's pass rate): f3 = forward word of its first 16
+					 * bases, r = reverse word of its last 16, exactly what the rolling registers held at that position.
+					 * Then both 38-bit strands from the two words: the forward code is the first 16 bases followed by
+					 * the last 3 (complement-reversed top 3 groups of the reverse word), the reverse-complement code is
+					 * the reverse word followed by the complement-reversed first 3. */
 					const uint2 q = queue[qn + lane];
 					const uint32_t f3 = q.x, r = q.y;
+					if (PER_READ) s1_pos = qpos[qn + lane];
 					const uint32_t tf = f3 >> 26, tr = r >> 26;
 					const uint32_t l3 = 63u ^ (((tr & 3u) << 4) | (tr & 0xCu) | (tr >> 4));
 					const uint32_t r3 = 63u ^ (((tf & 3u) << 4) | (tf & 0xCu) | (tf >> 4));
@@ -413,7 +428,6 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 					const uint32_t fo = ntsm_fold(((unsigned long long) s1_khi << 32) | s1_klo);
 					s1_g1 = ntsm_h1(fo);
 					s1_g2 = ntsm_h2(fo);
-					if (PER_READ) s1_pos = qpos[qn + lane];
 					/* second-level filter (L2 resident, exact canonical code, well-mixed hash): most first-level
 					 * false positives stop here instead of costing an Infinity-Cache access to the key table */
 					s1_pw = p.prefilter[s1_g1 >> p.pf_shift];
@@ -428,17 +442,24 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 			drain_step(false);                                 /* stage 3 */
 		};
 
-		/* Phase A of one 8-position block: roll, 12-mer order hashes, sliding minimum, k-mer bit hash;
-		 * decides per position whether the minimizer changed (nd) and issues the 8 filter-block loads
-		 * (lanes that keep their block all read block 0: one request per wave instruction). */
-		struct BlockState { uint32_t f3[8], r[8]; bool ok[8], nd[8]; uint4 bl[8]; };
+		/* Phase A of one 8-position block: roll, 12-mer order hashes, sliding minimum, k-mer bit hash; decides per
+		 * position whether the lane needs a new filter block and issues the 8 block loads.  The per-lane conditions
+		 * live in scalar registers as 64-bit wave masks (ballot / inverse ballot): one vector compare each for "window
+		 * has an invalid base" and "minimizer changed", the rest is scalar logic that runs beside the vector unit.
+		 *   bad   window invalid
+		 *   ld    valid, and the minimizer differs from the previous position's or the previous window was invalid
+		 *         (then nothing is cached): the lane requests its block; every other lane sends an out-of-range
+		 *         offset -- the buffer load returns 0 for it and makes no memory request
+		 *   sel   ld | bad: the lane replaces its cached block by what came back, which for a bad lane is 0: an
+		 *         invalid window then fails the bit test by itself and needs no mask of its own */
+		struct BlockState { uint32_t u[8], f3[8], r[8]; unsigned long long sel[8]; uint4 bl[8]; };
 		auto lut_reads = [&](const uint2 v, uint2 (&e8)[8]) {   /* the 8 table reads of one block issue together */
 			const uint32_t w[2] = { v.x, v.y };
 #pragma unroll
 			for (int j = 0; j < 8; ++j) e8[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
 		};
 		auto phase_a = [&](const uint2 (&e8)[8], BlockState &B) {
-			uint32_t gg[8], fh[8], idx[8], pm = 0xFFFFFFFFu;
+			uint32_t gg[8], fh[8], pm = 0xFFFFFFFFu;
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
 				NTSM_STEP(e8[j])
@@ -446,20 +467,27 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				gg[j] = NTSM_MMER_G();
 				pm = min(pm, gg[j]);
 				const uint32_t mz = j + 9 - NTSM_FAST_W <= 7 ? min(sprev[j + 9 - NTSM_FAST_W], pm) : pm;
+				B.u[j] = ntsm_kmer_sum(j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)), R);
 				B.f3[j] = j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2));
 				B.r[j] = R;
-				/* plain & / | (no short circuit): keeps this straight-line code instead of exec-masked regions.
-				 * A lane (re)loads when its window is valid and either the minimizer differs from the previous
-				 * position's or the previous window was invalid (then no block is cached for it). */
-				B.ok[j] = (inv & 0x7FFFFu) == 0;
-				B.nd[j] = B.ok[j] & ((mz != mz_prev) | !ok_prev);
-				idx[j] = B.nd[j] ? ntsm_block_off(mz, blk_map) : 0xFFFFFFFFu;   /* out of range: returns 0, no memory request */
+				const unsigned long long bad = __builtin_amdgcn_ballot_w64(run <= NTSM_FAST_K);
+				const unsigned long long ld = ~bad & (__builtin_amdgcn_ballot_w64(mz != mz_prev) | bad_prev);
+				B.sel[j] = ld | bad;
+				const uint32_t bi = ntsm_block_idx(mz, blk_map);
+#ifdef NTSM_ABLATION
+				/* 8: no lane requests a block (all out of range); 16: every lane requests block 0 (one request per load) */
+				/* 32 / 64: only 9/16 (5/16) of the runs request their block -- what an on-chip minimizer-set test would leave */
+				const bool keep = (p.debug & 32u) ? ((mz * 0x85EBCA6Bu) >> 28) < 9u : (p.debug & 64u) ? ((mz * 0x85EBCA6Bu) >> 28) < 5u : true;
+				const uint32_t idx = (p.debug & 8u) ? 0xFFFFFFFFu : (p.debug & 16u) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(ld) && keep) ? bi : 0xFFFFFFFFu;
+#else
+				const uint32_t idx = __builtin_amdgcn_inverse_ballot_w64(ld) ? bi : 0xFFFFFFFFu;
+#endif
 				mz_prev = mz;
-				ok_prev = B.ok[j];
-				nk += B.ok[j] ? 1u : 0u;
+				bad_prev = bad;
+				nk_s += (uint32_t) __popcll(~bad);
 				{   /* issue each block load as soon as its offset is known: earlier positions get the rest of the block as
 				     * cover (+2 % over issuing the eight loads together at the end of the phase) */
-					const u32x4v bv = __builtin_amdgcn_raw_buffer_load_b128(blk_rsrc, (int) idx[j], 0, 0);
+					const ntsm_u32x4 bv = ntsm_struct_buffer_load_b128(blk_rsrc, (int) idx, 0, 0, 0);
 					B.bl[j] = make_uint4(bv.x, bv.y, bv.z, bv.w);
 				}
 			}
@@ -468,18 +496,28 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #pragma unroll
 			for (int j = 6; j >= 9 - NTSM_FAST_W; --j) sprev[j] = min(gg[j], sprev[j + 1]);
 		};
-		/* Phase C: two-bit test against the (possibly just fetched) block; positives go to the queue */
+		/* Phase C: four-bit test against the (possibly just fetched) block.  word << field (NTSM_KBITn: bit 31 - field)
+		 * puts the tested bit in the sign position -- the shifter takes the low five bits of the selected byte, so the
+		 * fields need no mask -- and the sign of the AND of the four is the verdict.  Positives go to the wave's queue
+		 * as { forward word of the first 16 bases, reverse word of the last 16 }.  (Queueing tile offsets instead and
+		 * rebuilding the window from the tile bytes at drain time was measured: 3 fewer instructions per position in
+		 * this loop, 53.2 instead of 52.2 ms per 3e8 reads.) */
 		auto phase_c = [&](const BlockState &B, const int pos0) {
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
-				cur.x = B.nd[j] ? B.bl[j].x : cur.x;
-				cur.y = B.nd[j] ? B.bl[j].y : cur.y;
-				cur.z = B.nd[j] ? B.bl[j].z : cur.z;
-				cur.w = B.nd[j] ? B.bl[j].w : cur.w;
-				const uint32_t u = ntsm_kmer_sum(B.f3[j], B.r[j]), um = ntsm_kmer_mix(u);
-				const bool pass = B.ok[j] & (((cur.x >> NTSM_KBIT0(u)) & (cur.y >> NTSM_KBIT1(um)) & (cur.z >> NTSM_KBIT2(um)) &
-						(cur.w >> NTSM_KBIT3(um)) & 1u) != 0);
-				const unsigned long long m = __ballot(pass);
+				const bool sel = __builtin_amdgcn_inverse_ballot_w64(B.sel[j]);
+				cur.x = sel ? B.bl[j].x : cur.x;
+				cur.y = sel ? B.bl[j].y : cur.y;
+				cur.z = sel ? B.bl[j].z : cur.z;
+				cur.w = sel ? B.bl[j].w : cur.w;
+				const uint32_t u = B.u[j], um = ntsm_kmer_mix(u);
+				uint32_t s0, s1, s2, s3;
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s0) : "v"(u), "v"(cur.x));
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s1) : "v"(um), "v"(cur.y));
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(s2) : "v"(um), "v"(cur.z));
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(s3) : "v"(um), "v"(cur.w));
+				const bool pass = (int32_t) (__builtin_amdgcn_bitop3_b32(s0, s1, s2, 0x80) & s3) < 0;
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
 				if (m) {
 					if (pass) {
 						const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
@@ -505,12 +543,9 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #undef NTSM_MMER_G
 	}
 #pragma unroll
-	for (int off = 32; off > 0; off >>= 1) {
-		nk += __shfl_down(nk, off, 64);
-		nh += __shfl_down(nh, off, 64);
-	}
+	for (int off = 32; off > 0; off >>= 1) nh += __shfl_down(nh, off, 64);
 	if ((t & 63) == 0) {
-		if (nk) atomicAdd(p.totals + 0, p.sign * (unsigned long long) nk);
+		if (nk_s) atomicAdd(p.totals + 0, p.sign * (unsigned long long) nk_s);
 		if (nh) atomicAdd(p.totals + 1, p.sign * (unsigned long long) nh);
 	}
 }
@@ -698,7 +733,7 @@ struct ntsm_ctx {
 	uint64_t n_blocks = 0;                     /* number of 128-bit filter blocks: mult * 2^e, mult in {1, 3} */
 	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
 	uint32_t prefilter_log2 = 0;               /* log2(bits) */
-	NtsmBlockMap blk_map = { 0, 1, 0 };
+	NtsmBlockMap blk_map = { 1 };
 	/* tabulated k = 19 path (ntsm_tab_kernel.inc) */
 	NtsmTabEntry *d_tab = nullptr;
 	uint4 *d_tblocks = nullptr;
@@ -844,11 +879,8 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			}
 			if (e > 20) e = 20;
 			if (e < 4) e = 4;
-			const uint32_t slack = 24 - e < 6 ? 24 - e : 6;                   /* e + slack <= 24 (mul24 operand), slack >= 4 */
 			c->n_blocks = (uint64_t) mult << e;
-			c->blk_map.qshift = 32 - (e + slack);
-			c->blk_map.mult = mult;
-			c->blk_map.sshift = slack - 4;
+			c->blk_map.n_blocks = (uint32_t) c->n_blocks;
 			blocks.assign(c->n_blocks * 4, 0u);
 			for (uint32_t i = 0; i < n; ++i) {
 				const uint64_t x = c->canon[i];
@@ -864,7 +896,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 					mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
 				}
 				const uint32_t u = ntsm_kmer_sum((uint32_t) (x >> 6), (uint32_t) (rc >> 6)), um = ntsm_kmer_mix(u);
-				uint32_t *blk = &blocks[(ntsm_block_off(mz, c->blk_map) >> 4) * 4];
+				uint32_t *blk = &blocks[(size_t) ntsm_block_idx(mz, c->blk_map) * 4];
 				blk[0] |= 1u << NTSM_KBIT0(u);
 				blk[1] |= 1u << NTSM_KBIT1(um);
 				blk[2] |= 1u << NTSM_KBIT2(um);
@@ -1407,7 +1439,7 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 	{
 		uint2 lut64[256];
 		for (int i = 0; i < 256; ++i)
-			lut64[i] = lut[i] < 4 ? make_uint2((uint32_t) lut[i], 3u - lut[i]) : make_uint2(0u, 0x80000003u);
+			lut64[i] = lut[i] < 4 ? make_uint2((uint32_t) lut[i], (3u - lut[i]) | 0x10000u) : make_uint2(0u, 3u);   /* { code, complement | valid << 16 } */
 		if (hipMalloc(&c->d_lut64, sizeof lut64) != hipSuccess) return fail(NTSM_ERR_HIP);
 		if (hipMemcpy(c->d_lut64, lut64, sizeof lut64, hipMemcpyHostToDevice) != hipSuccess) return fail(NTSM_ERR_HIP);
 	}

@@ -32,12 +32,14 @@ int main(int argc, char **argv)
 {
 	ntsm::SiteSet S;
 	if (argc < 2 || !S.load(argv[1], 19, false, std::cerr)) return 1;
-	const uint32_t e = 16; NtsmBlockMap map; map.qshift = 32 - (e + 6); map.mult = 3; map.sshift = 2;   /* 3 * 2^16 blocks (3 MiB) */
+	const uint32_t e = 16; NtsmBlockMap map; map.n_blocks = 3u << e;   /* 3 * 2^16 blocks (3 MiB) */
 	const uint64_t n_blocks = 3ull << e;
 	std::vector<Scheme> schemes = {
 		{ "A: 4 words x 1 bit (current)", 0, 0, 0 },
 		{ "A-ideal: 4 words x 1 bit, four independent 64-bit-mixed hashes", 5, 0, 0 },
 		{ "A-um0: 4 words x 1 bit, bit 0 from um byte 0 instead of raw u byte 3", 6, 0, 0 },
+		{ "A6: 4 words, 1+1+2+2 bits (second bits from um2 = um * odd)", 7, 0, 0 },
+		{ "A8: 4 words x 2 bits", 8, 0, 0 },
 		{ "B: 1 word, rotr(0x00010001,s1)|rotr(0x00000021,s2)", 1, 0x00010001u, 0x00000021u },
 		{ "B: 1 word, rotr(0x00000101,s1)|rotr(0x00002001,s2)", 1, 0x00000101u, 0x00002001u },
 		{ "B: 1 word, rotr(0x00010001,s1)|rotr(0x00000801,s2) (3-4 bits)", 1, 0x00010001u, 0x00000801u },
@@ -63,6 +65,12 @@ int main(int argc, char **argv)
 				const uint32_t um = ntsm_kmer_mix(u);
 				m[0] = 1u << (um & 31u); m[1] = 1u << NTSM_KBIT1(um); m[2] = 1u << NTSM_KBIT2(um); m[3] = 1u << NTSM_KBIT3(um);
 				*w = 4;
+			} else if (sc.kind == 7 || sc.kind == 8) {
+				const uint32_t um = ntsm_kmer_mix(u), u2 = um * 0x85EBCA6Bu;
+				m[0] = 1u << NTSM_KBIT0(u); m[1] = 1u << NTSM_KBIT1(um); m[2] = 1u << NTSM_KBIT2(um); m[3] = 1u << NTSM_KBIT3(um);
+				m[2] |= 1u << (31u - ((u2 >> 24) & 31u)); m[3] |= 1u << (31u - ((u2 >> 16) & 31u));
+				if (sc.kind == 8) { m[0] |= 1u << (31u - ((u2 >> 8) & 31u)); m[1] |= 1u << (31u - (u2 & 31u)); }
+				*w = 4;
 			} else if (sc.kind == 0) {
 				const uint32_t um = ntsm_kmer_mix(u);
 				m[0] = 1u << NTSM_KBIT0(u); m[1] = 1u << NTSM_KBIT1(um); m[2] = 1u << NTSM_KBIT2(um); m[3] = 1u << NTSM_KBIT3(um);
@@ -82,7 +90,7 @@ int main(int argc, char **argv)
 		for (uint64_t x : S.keys) {
 			uint32_t w, m[4];
 			bits(x, &w, m);
-			uint32_t *b = &blk[(ntsm_block_off(minimizer(x), map) >> 4) * 4];
+			uint32_t *b = &blk[(size_t) ntsm_block_idx(minimizer(x), map) * 4];
 			if (w == 4) { b[0] |= m[0]; b[1] |= m[1]; b[2] |= m[2]; b[3] |= m[3]; }
 			else if (w & 8u) { b[w & 3u] |= m[0]; b[(w & 3u) ^ 2u] |= m[1]; }
 			else b[w] |= m[0];
@@ -98,8 +106,8 @@ int main(int argc, char **argv)
 			if (std::binary_search(sorted.begin(), sorted.end(), x)) continue;
 			uint32_t w, m[4];
 			bits(x, &w, m);
-			const uint32_t *b = &blk[(ntsm_block_off(minimizer(x), map) >> 4) * 4];
-			const bool hit = w == 4 ? ((b[0] & m[0]) && (b[1] & m[1]) && (b[2] & m[2]) && (b[3] & m[3]))
+			const uint32_t *b = &blk[(size_t) ntsm_block_idx(minimizer(x), map) * 4];
+			const bool hit = w == 4 ? ((b[0] & m[0]) == m[0] && (b[1] & m[1]) == m[1] && (b[2] & m[2]) == m[2] && (b[3] & m[3]) == m[3])
 			               : (w & 8u) ? ((b[w & 3u] & m[0]) == m[0] && (b[(w & 3u) ^ 2u] & m[1]) == m[1]) : ((b[w] & m[0]) == m[0]);
 			fp += hit;
 			++n;

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""tools/make_traffic.py <gpurun_out/prof_TAG> <profiles/rNN_traffic.json> <bases_per_launch>
+
+Turns the PMC passes of tools/profile.sh into the per-base constants bench.py quotes in `roofline.traffic`
+and `valu_busy_frac_from_pmc`.  The file carries the SHA-256 of the kernel sources it was measured on;
+bench.py reports traffic = null when the sources have changed since (no silently stale constants).
+HBM/fabric bytes follow /opt/skills/guides/MI355X_MICROARCH.md's rocprofv3 recipe: FETCH_SIZE and WRITE_SIZE
+from their own --pmc passes, in KiB; FETCH_SIZE tallies 16-byte-per-lane coalesced reads at half on gfx950,
+so half of the stream bytes are added back; the random 4/8/16-byte filter and table reads are left as counted."""
+import collections, csv, glob, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["ntsm_amd/csrc/ntsm_hip.hip", "ntsm_amd/csrc/ntsm_device.h", "ntsm_amd/csrc/ntsm_tab_kernel.inc"]
+
+
+def kernel_source_sha16():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    prof, out, bases = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    per = collections.defaultdict(list)
+    for f in sorted(glob.glob(os.path.join(prof, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            if "ntsm_count" in r.get("Kernel_Name", ""):
+                acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for name, d in acc.items():
+            vals = sorted(d.values())
+            per[name] = vals[len(vals) // 2]                     # median dispatch (all launches do the same work)
+    stream = bases * 151.0 / 150.0
+    fetch_raw, write = per["FETCH_SIZE"] * 1024.0, per["WRITE_SIZE"] * 1024.0
+    fetch = fetch_raw + 0.5 * stream
+    cycles = per["GRBM_GUI_ACTIVE"] / 8.0                        # summed over the 8 XCDs
+    doc = {
+        "source": "%s: separate rocprofv3 --pmc passes of tools/profile.sh (one counter group per pass, no trace domains)" % os.path.relpath(prof, ROOT),
+        "kernel_source_sha16": kernel_source_sha16(),
+        "bases_per_launch": bases,
+        "fetch_bytes_per_launch_raw": fetch_raw, "write_bytes_per_launch": write, "fetch_bytes_per_launch_corrected": fetch,
+        "correction": "+0.5 x stream bytes: FETCH_SIZE tallies 16-B/lane coalesced reads at half on gfx950; random 4/8/16-byte filter and table reads left as counted",
+        "traffic_bytes_per_base": (fetch + write) / bases,
+        "note": "fabric-side traffic (L2 misses): includes Infinity-Cache hits of the filters / key table; the read stream itself crosses HBM once",
+        "valu_insts_per_position": per["SQ_INSTS_VALU"] / (stream / 64.0) if per.get("SQ_INSTS_VALU") else None,
+        "valu_busy_frac": per["SQ_INSTS_VALU"] * 4.2 / (1024.0 * cycles) if per.get("SQ_INSTS_VALU") and cycles else None,
+        "valu_busy_note": "SQ_INSTS_VALU x 4.2 cycles per wave64 instruction (profiles/r02_microbench/valu_rate.txt) / (1024 SIMDs x GRBM_GUI_ACTIVE/8)",
+        "l2_requests_per_launch": per.get("TCC_REQ_sum"), "l2_misses_per_launch": per.get("TCC_MISS_sum"),
+        "l2_request_rate_frac_of_cap": (per["TCC_REQ_sum"] / (cycles / 2.4e9) / 266e9) if per.get("TCC_REQ_sum") and cycles else None,
+        "l2_cap_note": "cap = 266 G requests/s whatever the request width (profiles/r02_microbench/l2_policy.txt); time from GRBM_GUI_ACTIVE at 2.4 GHz",
+    }
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()
