@@ -211,7 +211,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "achieved_stream_only_GBs": bases_per_step * (READ_LEN + 1) / READ_LEN / launch_s / 1e9,
-                         "kernel": {0: "ntsm_count_k19_kernel", 2: "ntsm_count_k19_kernel", 3: "ntsm_count_tab19_kernel"}.get(args.kernel, "ntsm_count_kernel"),
+                         "kernel": {0: "ntsm_count_mz_kernel", 2: "ntsm_count_mz_kernel", 3: "ntsm_count_tab19_kernel"}.get(args.kernel, "ntsm_count_kernel"),
                          "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
                          "algorithmic_bytes_per_base": bytes_per_base,
                          "valu_busy_frac_from_pmc": valu_busy,     # share of SIMD issue cycles on VALU

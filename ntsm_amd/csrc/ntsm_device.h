@@ -49,6 +49,28 @@ NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC
 #define NTSM_FAST_W (NTSM_FAST_K - NTSM_FAST_M + 1)
 #define NTSM_MMER_MASK ((1u << (2 * NTSM_FAST_M)) - 1u)
 
+/* The same filter for other k (15 <= k <= 31, k != 19): what varies is which m-mers of the k-mer are minimizer
+ * candidates.  The candidate set must map onto itself under reverse complement, i.e. be symmetric in the k-mer:
+ *   k >= 19   12-mers, the 8 (k odd) or 9 (k even) innermost ones: offsets a .. a + w - 1 from either end,
+ *             a = (k - 12 - (w - 1)) / 2  (k = 19: all 8, a = 0)
+ *   k <  19   all 8 (k - 7)-mers
+ * so the sliding minimum always runs over 8 or 9 order hashes, computed `a` positions behind the newest base. */
+struct NtsmFastPlan { int mode; uint32_t k, m, w, a; };      /* mode: -1 no fast path, 0 the k = 19 kernel, 1 w = 8, 2 w = 9 */
+NTSM_DHD NtsmFastPlan ntsm_fast_plan(uint32_t k)
+{
+	NtsmFastPlan pl = { -1, k, 0u, 0u, 0u };
+	if (k == NTSM_FAST_K) { pl.mode = 0; pl.m = NTSM_FAST_M; pl.w = NTSM_FAST_W; }
+	else if (k >= 19 && k <= 31) { pl.m = 12; pl.w = (k & 1u) ? 8u : 9u; pl.a = (k - 12u - (pl.w - 1u)) / 2u; pl.mode = pl.w == 8 ? 1 : 2; }
+	else if (k >= 15 && k < 19) { pl.m = k - 7u; pl.w = 8; pl.mode = 1; }
+	return pl;
+}
+/* the two 32-bit words whose sum picks the filter bits: the k-mer's forward and reverse-complement codes, left-aligned
+ * (k >= 16: their top 32 bits = first 16 bases of either strand; together they cover all k bases for k <= 32) */
+NTSM_DHD uint32_t ntsm_code_top(unsigned long long code, uint32_t k)
+{
+	return k >= 16 ? (uint32_t) (code >> (2 * k - 32)) : (uint32_t) (code << (32 - 2 * k));
+}
+
 /* Order hash of a 12-mer: its canonical code (the smaller of the 24-bit forward and reverse-complement codes) times an
  * odd constant, low 32 bits of the 48-bit product (v_mul_u32_u24), compared as an integer.  Cheaper strand-symmetric
  * combiners were measured and lose (tools/sim_mmer_order.cpp, tools/filter_fp.cpp on the hs_n10_like set):
@@ -191,13 +213,14 @@ struct NtsmCountParams {
 	uint32_t kmask;                    /* low k bits set: window validity */
 	uint32_t fshift, bshift;           /* bit index = h1 >> fshift ; bucket = h >> bshift */
 	const uint8_t *lut;                /* 256-byte base table, vendor/KseqHashIterator.hpp:114-127 */
-	const uint2 *lut64;                /* fast path: per byte { code, (3 - code) | invalid << 31 } */
+	const uint2 *lut64;                /* fast path: per byte { code, (3 - code) | valid << 16 } */
 	const uint4 *blocks;               /* k = 19 fast path: minimizer-addressed 128-bit filter blocks */
 	NtsmBlockMap blk_map;              /* minimizer -> filter block offset */
 	const uint32_t *prefilter;         /* fast path, drain only: plain 2-bit Bloom over canonical codes (L2 resident) */
 	uint32_t pf_shift;                 /* word index = h1(fold) >> pf_shift; bits = h2(fold) & 31, (h2 >> 5) & 31 */
 	uint32_t debug;                    /* ablation switches (NTSM_DEBUG_KERNEL): 1 = drain discards its queue, 2 = drain stops after the k-mer rebuild */
 	uint32_t blk_bytes;                /* size of the filter in bytes (buffer descriptor range) */
+	uint32_t fk_k, fk_m2, fk_a2;       /* general-k fast path: k, 2 * minimizer length, 2 * candidate offset (NtsmFastPlan) */
 	/* tabulated k = 19 path */
 	const NtsmTabEntry *tab;           /* 256 entries, copied to LDS by every workgroup */
 	const uint4 *tblocks;              /* its minimizer-addressed 128-bit filter blocks */

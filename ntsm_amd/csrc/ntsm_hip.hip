@@ -233,16 +233,18 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(
 }
 
 /* --------------------------------------------------------------------------------------------
- * k = 19 fast path.  Same tiling as the generic kernel; per position a lane
- *   1. rolls fw / rc (two 32-bit words each) and the canonical 12-mer order hash,
- *   2. keeps the sliding minimum over the 8 12-mers of the 19-mer (block-decomposed: prefix minima
+ * Minimizer-blocked fast path: k = 19 with every constant folded, and 15 <= k <= 31
+ * with k as a run-time parameter (ntsm_fast_plan, ntsm_device.h).  Same tiling as the generic kernel; per
+ * position a lane
+ *   1. rolls the forward / reverse-complement words, the run of valid bases and the canonical m-mer order hash,
+ *   2. keeps the sliding minimum over the 8 (9) candidate m-mers of the k-mer (block-decomposed: prefix minima
  *      of the current 8-block against suffix minima of the previous one),
- *   3. re-reads its 64-bit filter block from L2 only when the minimizer changed,
- *   4. tests two block bits chosen by a strand-symmetric hash; positives are queued by tile offset
- *      in a wave-private LDS queue.
- * Whenever 64 positives are queued the wave drains them with every lane busy: the k-mer is rebuilt
- * from the tile bytes still in LDS, its canonical code looked up in the cuckoo table (bucket 2
- * only if bucket 1 is full), and the slot counter bumped with one 64-bit atomic.
+ *   3. re-reads its 128-bit filter block from L2 only when the minimizer changed,
+ *   4. tests four block bits chosen by a strand-symmetric hash; positives are queued as { forward word of the
+ *      first 16 bases, reverse word of the last 16 } in a wave-private LDS queue.
+ * Whenever 64 positives are queued the wave drains them with every lane busy: the canonical code is rebuilt
+ * from the two words, tested against the second-level filter, looked up in the cuckoo table (bucket 2 only if
+ * bucket 1 is full), and the slot counter bumped with one 64-bit atomic.
  * ------------------------------------------------------------------------------------------ */
 #ifndef NTSM_FAST_WAVES
 #define NTSM_FAST_WAVES 4                              /* waves per SIMD the register budget is held to */
@@ -260,10 +262,18 @@ __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
 	return row * kFastC + ((((byte_in_row >> 4) ^ (row >> 1)) & 7) << 4) + (byte_in_row & 15);
 }
 
-template <bool PER_READ>
-__global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_k19_kernel(const NtsmCountParams p)
+/* KMODE 0: k = 19 with every constant folded (the reference default and all BASELINE configurations).
+ * KMODE 1 / 2: any other k of ntsm_fast_plan(), 8 / 9 minimizer candidates; k, the minimizer length and the
+ * candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each). */
+template <int KMODE, bool PER_READ>
+__global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_mz_kernel(const NtsmCountParams p)
 {
 	constexpr int C = kFastC, VPT = C / 16, NB = C / 8;
+	constexpr bool GEN = KMODE != 0;
+	constexpr int W = KMODE == 0 ? NTSM_FAST_W : (KMODE == 1 ? 8 : 9);
+	const uint32_t gk = GEN ? p.fk_k : (uint32_t) NTSM_FAST_K;            /* wave-uniform run-time k of the general kernels */
+	const uint32_t g_a2 = p.fk_a2, g_mmask = (1u << p.fk_m2) - 1u, g_rsh = 64u - p.fk_m2 - p.fk_a2, g_fsh = 64u - 2u * gk;
+	const uint32_t g_rmask = gk >= 16 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (32u - 2u * gk);
 	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * C];
 	__shared__ uint2 lut64[256];
 	__shared__ uint2 queue_all[kThreads / 64][kQueueCap];          /* positives: { first-16 forward word, last-16 reverse word } */
@@ -323,32 +333,47 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		 * per base; the 19-mer's two strands are covered by F three positions ago (its first 16 bases) and
 		 * the current R (its last 16, reversed); the window is valid when run > 19. */
 		uint32_t F = 0, R = 0, run = 1;
+		uint32_t Fh = 0, Ro = 0;                            /* general k: bases 17..32 back of the forward word, of the reverse word */
 		uint32_t sprev[8];                                  /* suffix minima of the previous 8-block, [1..7] used */
-		uint32_t fc0, fc1, fc2;                             /* F at the three positions before the current block */
+		uint32_t fc0 = 0, fc1 = 0, fc2 = 0;                 /* k = 19: F at the three positions before the current block */
 		uint32_t qn = 0;                                    /* wave-uniform queue fill */
 #define NTSM_STEP(e_)                                                                     \
 		{                                                                                 \
+			if (GEN) {                                                                    \
+				Fh = __builtin_amdgcn_alignbit(Fh, F, 30);                                \
+				Ro = __builtin_amdgcn_alignbit(R, Ro, 2);                                 \
+			}                                                                             \
 			NTSM_F_UPDATE((e_).x)                                                         \
 			R = __builtin_amdgcn_alignbit((e_).y, R, 2);                                  \
 			asm("v_mad_u32_u16 %0, %1, %2, 1 op_sel:[0,1,0,0]" : "=v"(run) : "v"(run), "v"((e_).y)); \
 		}
-#define NTSM_MMER_G() ntsm_mmer_hash(min(F & NTSM_MMER_MASK, R >> (32 - 2 * NTSM_FAST_M)))
-		{   /* warm-up: the 18 bytes in front of the chunk; 12-mer hashes of positions -7..-1 */
+		/* order hash of the newest candidate m-mer: the one ending `a` bases behind the newest base */
+		auto mmer_g = [&]() -> uint32_t {
+			if (!GEN) return ntsm_mmer_hash(min(F & NTSM_MMER_MASK, R >> (32 - 2 * NTSM_FAST_M)));
+			const uint32_t fm = __builtin_amdgcn_alignbit(Fh, F, g_a2) & g_mmask;
+			const uint32_t rm = (uint32_t) (((((unsigned long long) R) << 32) | Ro) >> g_rsh) & g_mmask;
+			return ntsm_mmer_hash(min(fm, rm));
+		};
+		/* forward word of the window's first 16 bases (k < 16: its code, left-aligned) */
+		auto f_top = [&]() -> uint32_t { return (uint32_t) ((((((unsigned long long) Fh) << 32) | F) << g_fsh) >> 32); };
+#define NTSM_MMER_G() mmer_g()
+		{   /* warm-up: the k - 1 bytes in front of the chunk (general k: all 32 of the prefix row, the run counter takes care of
+		     * what lies before a window); order hashes of the last W - 1 positions */
 			const uint4 v0 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 32));
 			const uint4 v1 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 16));
 			const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
 			uint32_t gw[8], fh[32];
 #pragma unroll
-			for (int i = 14; i < 32; ++i) {
+			for (int i = GEN ? 0 : 32 - (NTSM_FAST_K - 1); i < 32; ++i) {
 				const uint2 e = lut64[(w[i >> 2] >> ((i & 3) * 8)) & 0xFFu];
 				NTSM_STEP(e)
 				fh[i] = F;
-				if (i >= 24 + (9 - NTSM_FAST_W)) gw[i - 24] = NTSM_MMER_G();   /* the last W-1 positions of the previous 8-block */
+				if (i >= 24 + (9 - W)) gw[i - 24] = NTSM_MMER_G();   /* the last W-1 positions of the previous 8-block */
 			}
 			fc0 = fh[29]; fc1 = fh[30]; fc2 = fh[31];
 			sprev[7] = gw[7];
 #pragma unroll
-			for (int i = 6; i >= 9 - NTSM_FAST_W; --i) sprev[i] = min(gw[i], sprev[i + 1]);
+			for (int i = 6; i >= 9 - W; --i) sprev[i] = min(gw[i], sprev[i + 1]);
 		}
 		uint32_t mz_prev = 0;
 		uint4 cur = make_uint4(0, 0, 0, 0);                  /* the lane's cached 128-bit filter block */
@@ -417,14 +442,33 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 					const uint2 q = queue[qn + lane];
 					const uint32_t f3 = q.x, r = q.y;
 					if (PER_READ) s1_pos = qpos[qn + lane];
-					const uint32_t tf = f3 >> 26, tr = r >> 26;
-					const uint32_t l3 = 63u ^ (((tr & 3u) << 4) | (tr & 0xCu) | (tr >> 4));
-					const uint32_t r3 = 63u ^ (((tf & 3u) << 4) | (tf & 0xCu) | (tf >> 4));
-					const uint32_t a_hi = tf, a_lo = (f3 << 6) | l3;
-					const uint32_t b_hi = tr, b_lo = (r << 6) | r3;
-					const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
-					s1_klo = lt ? a_lo : b_lo;
-					s1_khi = lt ? a_hi : b_hi;
+					if (!GEN) {
+						const uint32_t tf = f3 >> 26, tr = r >> 26;
+						const uint32_t l3 = 63u ^ (((tr & 3u) << 4) | (tr & 0xCu) | (tr >> 4));
+						const uint32_t r3 = 63u ^ (((tf & 3u) << 4) | (tf & 0xCu) | (tf >> 4));
+						const uint32_t a_hi = tf, a_lo = (f3 << 6) | l3;
+						const uint32_t b_hi = tr, b_lo = (r << 6) | r3;
+						const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
+						s1_klo = lt ? a_lo : b_lo;
+						s1_khi = lt ? a_hi : b_hi;
+					} else {
+						/* general k: the same from the left-aligned words.  k >= 16: each strand = its 16-base word followed
+						 * by the k - 16 bases only the other word holds = the complement of that word's top k - 16 groups in
+						 * reverse order (bit reversal + swap inside the pairs reverses the groups) */
+						unsigned long long fw, rv;
+						if (gk >= 16) {
+							auto crev = [](uint32_t x) { const uint32_t y = __builtin_bitreverse32(~x); return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1); };
+							const uint32_t g2 = 2u * gk - 32u, lowmask = (1u << g2) - 1u;       /* g2 <= 30 */
+							fw = ((unsigned long long) f3 << g2) | (crev(r) & lowmask);
+							rv = ((unsigned long long) r << g2) | (crev(f3) & lowmask);
+						} else {
+							fw = f3 >> (32u - 2u * gk);
+							rv = r >> (32u - 2u * gk);
+						}
+						const unsigned long long key = fw < rv ? fw : rv;
+						s1_klo = (uint32_t) key;
+						s1_khi = (uint32_t) (key >> 32);
+					}
 					const uint32_t fo = ntsm_fold(((unsigned long long) s1_khi << 32) | s1_klo);
 					s1_g1 = ntsm_h1(fo);
 					s1_g2 = ntsm_h2(fo);
@@ -466,11 +510,11 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				fh[j] = F;
 				gg[j] = NTSM_MMER_G();
 				pm = min(pm, gg[j]);
-				const uint32_t mz = j + 9 - NTSM_FAST_W <= 7 ? min(sprev[j + 9 - NTSM_FAST_W], pm) : pm;
-				B.u[j] = ntsm_kmer_sum(j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)), R);
-				B.f3[j] = j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2));
-				B.r[j] = R;
-				const unsigned long long bad = __builtin_amdgcn_ballot_w64(run <= NTSM_FAST_K);
+				const uint32_t mz = j + 9 - W <= 7 ? min(sprev[j + 9 - W], pm) : pm;
+				B.f3[j] = GEN ? f_top() : (j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)));
+				B.r[j] = GEN ? (R & g_rmask) : R;
+				B.u[j] = ntsm_kmer_sum(B.f3[j], B.r[j]);
+				const unsigned long long bad = __builtin_amdgcn_ballot_w64(run <= gk);
 				const unsigned long long ld = ~bad & (__builtin_amdgcn_ballot_w64(mz != mz_prev) | bad_prev);
 				B.sel[j] = ld | bad;
 				const uint32_t bi = ntsm_block_idx(mz, blk_map);
@@ -494,7 +538,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 			fc0 = fh[5]; fc1 = fh[6]; fc2 = fh[7];
 			sprev[7] = gg[7];
 #pragma unroll
-			for (int j = 6; j >= 9 - NTSM_FAST_W; --j) sprev[j] = min(gg[j], sprev[j + 1]);
+			for (int j = 6; j >= 9 - W; --j) sprev[j] = min(gg[j], sprev[j + 1]);
 		};
 		/* Phase C: four-bit test against the (possibly just fetched) block.  word << field (NTSM_KBITn: bit 31 - field)
 		 * puts the tested bit in the sign position -- the shifter takes the low five bits of the selected byte, so the
@@ -862,11 +906,12 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			filter[bit >> 5] |= 1u << (bit & 31);
 		}
 	};
+	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k);
 	auto build_blocks = [&]() {
-		/* k = 19: minimizer-addressed blocked filter.  Size = smallest of {2^e, 3 * 2^(e-2)} blocks with at least
-		 * 12 bits per key: 3 MiB for the 1.54 M-key human set -- it must leave room in the 4 MiB per-XCD L2 for the
-		 * read stream and the bucket lines, a full 4 MiB filter misses L2 on 18 % of its reads. */
-		if (c->k == NTSM_FAST_K) {
+		/* minimizer-addressed blocked filter (k = 19 and the other k of ntsm_fast_plan).  Size = smallest of {2^e,
+		 * 3 * 2^(e-2)} blocks with at least 12 bits per key: 3 MiB for the 1.54 M-key human set -- it must leave room in the
+		 * 4 MiB per-XCD L2 for the read stream and the bucket lines, a full 4 MiB filter misses L2 on 18 % of its reads. */
+		if (plan.mode >= 0) {
 			uint32_t e = 6, mult = 1;
 			if (filter_log2_req >= 100 && filter_log2_req <= 130) {          /* 100 + v: 3 * 2^v bits */
 				mult = 3; e = (uint32_t) (filter_log2_req - 100) - 7;
@@ -884,18 +929,19 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			blocks.assign(c->n_blocks * 4, 0u);
 			for (uint32_t i = 0; i < n; ++i) {
 				const uint64_t x = c->canon[i];
-				/* reverse complement of the 38-bit code: complement, then reverse the 2-bit groups of the 64-bit word */
+				/* reverse complement of the 2k-bit code: complement, then reverse the 2-bit groups of the 64-bit word */
 				uint64_t rc = ~x;
 				rc = ((rc >> 2) & 0x3333333333333333ull) | ((rc & 0x3333333333333333ull) << 2);
 				rc = ((rc >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((rc & 0x0F0F0F0F0F0F0F0Full) << 4);
-				rc = __builtin_bswap64(rc) >> (64 - 2 * NTSM_FAST_K);
+				rc = __builtin_bswap64(rc) >> (64 - 2 * plan.k);
+				const uint32_t mmask = (1u << (2 * plan.m)) - 1u;
 				uint32_t mz = 0xFFFFFFFFu;
-				for (int j = 0; j < NTSM_FAST_W; ++j) {                 /* the m-mer at offset j and its reverse complement */
-					const uint32_t sub = (uint32_t) (x >> (2 * j)) & NTSM_MMER_MASK;
-					const uint32_t rsub = (uint32_t) (rc >> (2 * (NTSM_FAST_K - NTSM_FAST_M - j))) & NTSM_MMER_MASK;
+				for (uint32_t j = plan.a; j < plan.a + plan.w; ++j) {     /* the candidate m-mer at offset j from the end, and its reverse complement */
+					const uint32_t sub = (uint32_t) (x >> (2 * j)) & mmask;
+					const uint32_t rsub = (uint32_t) (rc >> (2 * (plan.k - plan.m - j))) & mmask;
 					mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
 				}
-				const uint32_t u = ntsm_kmer_sum((uint32_t) (x >> 6), (uint32_t) (rc >> 6)), um = ntsm_kmer_mix(u);
+				const uint32_t u = ntsm_kmer_sum(ntsm_code_top(x, plan.k), ntsm_code_top(rc, plan.k)), um = ntsm_kmer_mix(u);
 				uint32_t *blk = &blocks[(size_t) ntsm_block_idx(mz, c->blk_map) * 4];
 				blk[0] |= 1u << NTSM_KBIT0(u);
 				blk[1] |= 1u << NTSM_KBIT1(um);
@@ -910,7 +956,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	auto build_prefilter = [&]() {
 		/* second-level filter of the fast path: plain Bloom, 2 bits per key in one 32-bit word, >= 5 bits per key
 		 * (1 MiB for the human set: with the 3 MiB first level it still fits the 4 MiB per-XCD L2) */
-		if (c->k == NTSM_FAST_K) {
+		if (plan.mode >= 0) {
 			uint32_t pl = 10;
 			while (pl < 28 && (1ull << pl) < 5ull * n) ++pl;
 #ifdef NTSM_ABLATION
@@ -1093,7 +1139,9 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 #endif
 	p.pf_shift = 32 - (c->prefilter_log2 - 5);
 	p.blk_bytes = (uint32_t) (c->n_blocks * 16);
-	const bool fast = c->k == NTSM_FAST_K && c->d_blocks && c->kernel_variant != 1;
+	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k);
+	const bool fast = plan.mode >= 0 && c->d_blocks && c->kernel_variant != 1;
+	p.fk_k = plan.k; p.fk_m2 = 2 * plan.m; p.fk_a2 = 2 * plan.a;
 	const bool tab = fast && !per_read && c->tab_ok && c->d_tblocks && c->kernel_variant == 3;
 	NtsmCountParams pt = p;                                 /* the tabulated kernel's view: 64 KiB tiles, segments of kTabSegTiles */
 	uint64_t tab_tiles = 0, tab_segs = 0;
@@ -1212,13 +1260,18 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		/* whatever follows on the launch stream (the list walker, the timing event, the caller's sync) sees the look-ups done */
 		HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[(tab_segs - 1) & 1], 0));
 		if (tab_segs > 1) HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[tab_segs & 1], 0));
-		hipLaunchKernelGGL((ntsm_count_k19_kernel<false>), dim3((unsigned) std::min<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles)), dim3(kThreads), 0, st, p);
+		hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false>), dim3((unsigned) std::min<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles)), dim3(kThreads), 0, st, p);
 		c->n_launch[0]++;
-	} else if (fast && per_read) {
-		hipLaunchKernelGGL((ntsm_count_k19_kernel<true>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
-		c->n_launch[1]++;
 	} else if (fast) {
-		hipLaunchKernelGGL((ntsm_count_k19_kernel<false>), dim3((unsigned) grid), dim3(kThreads), 0, st, p);
+		const dim3 g((unsigned) grid), b(kThreads);
+		switch (plan.mode * 2 + (per_read ? 1 : 0)) {
+		case 0: hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false>), g, b, 0, st, p); break;
+		case 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<0, true>), g, b, 0, st, p); break;
+		case 2: hipLaunchKernelGGL((ntsm_count_mz_kernel<1, false>), g, b, 0, st, p); break;
+		case 3: hipLaunchKernelGGL((ntsm_count_mz_kernel<1, true>), g, b, 0, st, p); break;
+		case 4: hipLaunchKernelGGL((ntsm_count_mz_kernel<2, false>), g, b, 0, st, p); break;
+		default: hipLaunchKernelGGL((ntsm_count_mz_kernel<2, true>), g, b, 0, st, p); break;
+		}
 		c->n_launch[1]++;
 	}
 	else if (per_read) {

@@ -246,6 +246,59 @@ def test_other_k_random_vs_oracle(nt, tmp_path):
         ctx.close()
 
 
+def test_minimizer_fast_path_every_k(nt, tmp_path):
+    """Every k the minimizer-blocked kernel takes besides 19 (15..31, ntsm_fast_plan in ntsm_device.h: 8 or 9 candidate
+    m-mers, candidate offset, 64-bit rolling words) against the oracle and against the generic kernel on the same input:
+    random sites, reads cut from them with substitutions, N, lower case and junk, read lengths around k; the launch
+    counters show which kernel ran.  Also the per-read (-m) instantiation: a threshold that trips mid-stream."""
+    rng = np.random.default_rng(77)
+    for k in range(15, 32):
+        path = str(tmp_path / ("s%d.fa" % k))
+        seqs = ["".join(rng.choice(list("ACGT"), size=2 * k + 9)) for _ in range(300)]
+        with open(path, "w") as f:
+            for i, sq in enumerate(seqs):
+                f.write(">s%d\n%s\n" % (i // 2, sq))
+        sites = nt.Sites(path, k=k, allow_dupes=True)
+        fp = OracleFP(path, k=k, dupes=True)
+        reads = []
+        for i in range(3000):
+            src = seqs[rng.integers(len(seqs))]
+            a = rng.integers(0, k + 5)
+            body = list(src[a:a + rng.integers(k - 2, 2 * k + 9)])
+            if rng.random() < 0.3 and body:
+                body[rng.integers(len(body))] = "ACGTNacgtn*"[rng.integers(11)]
+            if rng.random() < 0.2:
+                body = [c.lower() for c in body]
+            tail = "".join(rng.choice(list("ACGTN"), size=rng.integers(0, 3 * k), p=[.245, .245, .245, .245, .02]))
+            reads.append(("".join(body) + tail).encode())
+        bases, ends = nt.capi.flatten_reads(reads)
+        fp.process_flat(bases, ends)
+        want = fp.kmers()[2]
+        for variant in (0, 1):
+            ctx = nt.Context(sites.keys, k=k)
+            ctx.set_kernel(variant)
+            ctx.submit(bases, ends)
+            t = ctx.sync()
+            st = ctx.debug_stats()
+            assert (st["launches_k19"] > 0) == (variant == 0) and (st["launches_generic"] > 0) == (variant == 1), (k, st)
+            assert np.array_equal(ctx.counts(), want), (k, variant)
+            assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases), (k, variant)
+            ctx.close()
+        # -m: stop after the first read that lifts the hits above half of the total
+        thr = fp.total_hits // 2
+        fm = OracleFP(path, k=k, dupes=True, cov=2.0 * (thr + 0.5) / len(sites.keys))
+        assert fm.max_hits == thr
+        fm.process_flat(bases, ends)
+        assert fm.early_term
+        ctx = nt.Context(sites.keys, k=k, max_hits=thr)
+        ctx.submit(bases, ends)
+        t = ctx.sync()
+        assert t.early_stop == 1 and t.reads_consumed == fm.reads_processed, k
+        assert np.array_equal(ctx.counts(), fm.kmers()[2]), k
+        assert (t.total_kmers, t.total_hits, t.total_bases) == (fm.total_kmers, fm.total_hits, fm.total_bases), k
+        ctx.close()
+
+
 def test_early_stop_resident_and_batched(nt, n10):
     """-m semantics on the GPU: stop after the first read that lifts total hits strictly above the
     threshold, wherever the batch boundaries are; reads after it contribute nothing."""

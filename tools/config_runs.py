@@ -94,3 +94,29 @@ if "stress1" in which:                                   # one filter size per p
     print(json.dumps({"config": "configs[4] stress: %d sites, %d k-mers" % (n_sites, len(sites.keys)), "filter_log2": flog or "auto",
                       "reads": n_reads, "kernel_ms": kms, "gbases_per_s": n_reads * 150 / (kms / 1e3) / 1e9, "hits_per_pass": t.total_hits // 2}))
     ctx.close()
+
+if "ksweep" in which:                                    # other k through the minimizer-blocked kernel and through the generic one
+    n_reads = int(float(os.environ.get("NTSM_KSWEEP_READS", 1e8)))
+    ks = [int(x) for x in os.environ.get("NTSM_KSWEEP_K", "15,16,17,18,19,20,21,23,25,27,29,31").split(",")]
+    for k in ks:
+        sp = os.path.join(tmp, "k%d.fa" % k)
+        s = ntsm_amd.SynthShort(20241218, 96287, k=k, read_seed=7, sites_path=sp)
+        sites = ntsm_amd.Sites(sp, k=k)
+        d_win = torch.from_numpy(s.windows).to(dev)
+        d_bases = torch.empty(n_reads * s.stride, dtype=torch.uint8, device=dev)
+        s.device_fill(d_win.data_ptr(), 0, n_reads, d_bases.data_ptr()); torch.cuda.synchronize()
+        row = {"config": "k sweep: 96287 sites (window 31), %g reads of 150 bp" % n_reads, "k": k, "site_kmers": len(sites.keys)}
+        ref = None
+        for variant, name in ((0, "minimizer_kernel"), (1, "generic_kernel")):
+            ctx = ntsm_amd.Context(sites.keys, k=k)
+            ctx.set_kernel(variant)
+            t, dt, kms = timed_pass(ctx, d_bases, d_bases.numel(), None, n_reads, reps=2)
+            row[name + "_ms"] = kms
+            row[name + "_gbases_per_s"] = n_reads * 150 / (kms / 1e3) / 1e9
+            cur = (t.total_kmers, t.total_hits)
+            assert ref is None or cur == ref, (k, cur, ref)      # both kernels count the same
+            ref = cur
+            ctx.close()
+        row["hits_per_pass"] = ref[1] // 2
+        print(json.dumps(row), flush=True)
+        del d_bases
