@@ -121,7 +121,11 @@ int ntsm_staging_pool(uint64_t bytes);
 
 /* Count a batch already RESIDENT in device memory (d_bases 16-byte aligned).  d_read_end may be
  * NULL when the context has no early stop armed (max_hits == 0).  sign = +1 counts, -1 removes
- * the batch's contribution again (exact: integer adds).  Asynchronous on the context's stream. */
+ * the batch's contribution again (exact: integer adds).  Asynchronous on the context's stream.
+ * The kernels read the stream in aligned 16-byte granules: when n_bytes is not a multiple of 16 the last
+ * granule is read whole, up to 15 bytes past n_bytes.  Those bytes are ignored and the access cannot fault
+ * (an aligned granule never leaves the page of its first, valid byte), but tools that track allocations
+ * byte-exactly will want the buffer padded to a multiple of 16. */
 int ntsm_count_resident(ntsm_ctx *ctx, const void *d_bases, uint64_t n_bytes, const void *d_read_end,
 		uint64_t n_reads, int sign);
 

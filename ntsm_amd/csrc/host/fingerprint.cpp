@@ -92,8 +92,10 @@ void Feeder::flush()
 		rc = ntsm_sync(m_ctx, &t);
 		if (rc) die(rc, "sync failed");
 		if (t.early_stop) {
+			/* the reference prints m_totalReads here, a counter it only advances under -vvv and only after a read has been
+			 * processed (src/FingerPrint.hpp:70-72): 0 for -v / -vv, the reads before the crossing one for -vvv */
 			if (m_opt.verbose > 0)
-				std::cerr << "max count reached at " << t.reads_consumed << " reads, " << t.total_kmers
+				std::cerr << "max count reached at " << (m_opt.verbose > 2 ? t.reads_consumed - 1 : 0) << " reads, " << t.total_kmers
 				          << " k-mers, " << t.total_hits << " total counts, and " << t.total_bases
 				          << " total bases " << std::endl;
 			m_earlyTerm = true;

@@ -171,5 +171,14 @@ int main(int argc, char *argv[])
 	std::cerr << fp.printInfoSummary() << std::endl;
 	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	std::cerr << "Time: " << secs << " s Memory: " << rss_kb() << " kbytes" << std::endl;
+	/* Everything is printed.  Tearing down the context, the lanes, the pinned pool and the HIP runtime in order costs
+	 * 0.13 s (tools/e2e_threads.py) and gives nothing back that the kernel driver does not reclaim at exit anyway, so
+	 * leave without it; NTSM_CLEAN_EXIT=1 runs the destructors (leak checks). */
+	if (!getenv("NTSM_CLEAN_EXIT")) {
+		std::cout.flush();
+		std::cerr.flush();
+		fflush(nullptr);
+		_exit(0);
+	}
 	return 0;
 }
