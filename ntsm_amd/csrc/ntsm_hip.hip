@@ -251,24 +251,34 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(
 #endif
 /* forward word update in one v_lshl_or_b32 (hipcc emits shift + or for the C expression: +1 %) */
 #define NTSM_F_UPDATE(c_) asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(F) : "v"(F), "v"(c_));
-constexpr int kFastC = 128;
+#ifndef NTSM_FAST_C
+#define NTSM_FAST_C 128                                /* stream bytes per thread and tile of the minimizer-blocked kernels (128 or 96) */
+#endif
+#ifndef NTSM_STEP_POS
+#define NTSM_STEP_POS 8                                /* positions between issuing the filter-block loads and testing them (8 or 4) */
+#endif
+constexpr int kFastC = NTSM_FAST_C;
+constexpr int kListC = 128;                            /* list mode (tiles handed over by the tabulated kernel): always 32 KiB tiles */
 constexpr int kQueueCap = 128;                         /* < 64 left over + one position's burst of <= 64 */
 
-/* LDS image of a tile: row r (128 B) = stream bytes of thread r-1 (row 0 = the 32 bytes in front of
- * the tile, in its last two slots).  16-byte slot s of row r sits at physical slot s ^ ((r >> 1) & 7):
- * the per-thread ds_read_b128/b64 of "slot s of my row" is then bank-conflict free without padding. */
+/* LDS image of a tile: row r (C bytes) = stream bytes of thread r-1 (row 0 = the 32 bytes in front of the tile, in its
+ * last two slots).  The 16-byte slots of a row are permuted per row so that the per-thread ds_read_b64 of "slot s of my
+ * row" spreads over the banks without padding: C = 128: slot s sits at s ^ ((r >> 1) & 7) (conflict free); other C:
+ * rotated by r >> 3 (two-way). */
+template <int C>
 __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
 {
-	return row * kFastC + ((((byte_in_row >> 4) ^ (row >> 1)) & 7) << 4) + (byte_in_row & 15);
+	if (C == 128) return row * C + ((((byte_in_row >> 4) ^ (row >> 1)) & 7) << 4) + (byte_in_row & 15);
+	return row * C + (int) ((((uint32_t) (byte_in_row >> 4) + ((uint32_t) row >> 3)) % (uint32_t) (C / 16)) << 4) + (byte_in_row & 15);
 }
 
 /* KMODE 0: k = 19 with every constant folded (the reference default and all BASELINE configurations).
  * KMODE 1 / 2: any other k of ntsm_fast_plan(), 8 / 9 minimizer candidates; k, the minimizer length and the
  * candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each). */
-template <int KMODE, bool PER_READ>
+template <int KMODE, bool PER_READ, int C>
 __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_mz_kernel(const NtsmCountParams p)
 {
-	constexpr int C = kFastC, VPT = C / 16, NB = C / 8;
+	constexpr int VPT = C / 16, NB = C / 8, HB = NTSM_STEP_POS;
 	constexpr bool GEN = KMODE != 0;
 	constexpr int W = KMODE == 0 ? NTSM_FAST_W : (KMODE == 1 ? 8 : 9);
 	const uint32_t gk = GEN ? p.fk_k : (uint32_t) NTSM_FAST_K;            /* wave-uniform run-time k of the general kernels */
@@ -310,19 +320,19 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #else
 				const u32x4 nt = *reinterpret_cast<const u32x4 *>(p.base + ts + 16ll * v);
 #endif
-				*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr(1 + v / VPT, (v % VPT) * 16)) = make_uint4(nt.x, nt.y, nt.z, nt.w);
+				*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr<C>(1 + v / VPT, (v % VPT) * 16)) = make_uint4(nt.x, nt.y, nt.z, nt.w);
 			}
 		} else {
 #pragma unroll 1
 			for (int q = 0; q < VPT; ++q) {
 				const int v = t + kThreads * q;
 				const uint4 r = ntsm_load_vec(p, ts + 16ll * v);
-				*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr(1 + v / VPT, (v % VPT) * 16)) = r;
+				*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr<C>(1 + v / VPT, (v % VPT) * 16)) = r;
 			}
 		}
 		if (t < 2) {
 			const uint4 r = ntsm_load_vec(p, ts - 32 + 16 * t);
-			*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr(0, C - 32 + 16 * t)) = r;
+			*reinterpret_cast<uint4 *>(tile + ntsm_tile_addr<C>(0, C - 32 + 16 * t)) = r;
 		}
 		__syncthreads();
 
@@ -359,8 +369,8 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #define NTSM_MMER_G() mmer_g()
 		{   /* warm-up: the k - 1 bytes in front of the chunk (general k: all 32 of the prefix row, the run counter takes care of
 		     * what lies before a window); order hashes of the last W - 1 positions */
-			const uint4 v0 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 32));
-			const uint4 v1 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr(t, C - 16));
+			const uint4 v0 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr<C>(t, C - 32));
+			const uint4 v1 = *reinterpret_cast<const uint4 *>(tile + ntsm_tile_addr<C>(t, C - 16));
 			const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
 			uint32_t gw[8], fh[32];
 #pragma unroll
@@ -496,27 +506,28 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		 *         offset -- the buffer load returns 0 for it and makes no memory request
 		 *   sel   ld | bad: the lane replaces its cached block by what came back, which for a bad lane is 0: an
 		 *         invalid window then fails the bit test by itself and needs no mask of its own */
-		struct BlockState { uint32_t u[8], f3[8], r[8]; unsigned long long sel[8]; uint4 bl[8]; };
-		auto lut_reads = [&](const uint2 v, uint2 (&e8)[8]) {   /* the 8 table reads of one block issue together */
+		struct BlockState { uint32_t u[HB], f3[HB], r[HB]; unsigned long long sel[HB]; uint4 bl[HB]; };   /* one step: HB positions */
+		auto lut_reads = [&](const uint2 v, const int j0, uint2 (&e)[HB]) {   /* the table reads of one step issue together */
 			const uint32_t w[2] = { v.x, v.y };
 #pragma unroll
-			for (int j = 0; j < 8; ++j) e8[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
+			for (int jj = 0; jj < HB; ++jj) { const int j = j0 + jj; e[jj] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]; }
 		};
-		auto phase_a = [&](const uint2 (&e8)[8], BlockState &B) {
-			uint32_t gg[8], fh[8], pm = 0xFFFFFFFFu;
+		/* gg / fh / pm: order hashes, forward words and prefix minimum of the current 8-block (they outlive a 4-position step) */
+		auto phase_a = [&](const uint2 (&e)[HB], BlockState &B, const int j0, uint32_t (&gg)[8], uint32_t (&fh)[8], uint32_t &pm) {
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				NTSM_STEP(e8[j])
+			for (int jj = 0; jj < HB; ++jj) {
+				const int j = j0 + jj;
+				NTSM_STEP(e[jj])
 				fh[j] = F;
 				gg[j] = NTSM_MMER_G();
 				pm = min(pm, gg[j]);
 				const uint32_t mz = j + 9 - W <= 7 ? min(sprev[j + 9 - W], pm) : pm;
-				B.f3[j] = GEN ? f_top() : (j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)));
-				B.r[j] = GEN ? (R & g_rmask) : R;
-				B.u[j] = ntsm_kmer_sum(B.f3[j], B.r[j]);
+				B.f3[jj] = GEN ? f_top() : (j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)));
+				B.r[jj] = GEN ? (R & g_rmask) : R;
+				B.u[jj] = ntsm_kmer_sum(B.f3[jj], B.r[jj]);
 				const unsigned long long bad = __builtin_amdgcn_ballot_w64(run <= gk);
 				const unsigned long long ld = ~bad & (__builtin_amdgcn_ballot_w64(mz != mz_prev) | bad_prev);
-				B.sel[j] = ld | bad;
+				B.sel[jj] = ld | bad;
 				const uint32_t bi = ntsm_block_idx(mz, blk_map);
 #ifdef NTSM_ABLATION
 				/* 8: no lane requests a block (all out of range); 16: every lane requests block 0 (one request per load) */
@@ -532,9 +543,11 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				{   /* issue each block load as soon as its offset is known: earlier positions get the rest of the block as
 				     * cover (+2 % over issuing the eight loads together at the end of the phase) */
 					const ntsm_u32x4 bv = ntsm_struct_buffer_load_b128(blk_rsrc, (int) idx, 0, 0, 0);
-					B.bl[j] = make_uint4(bv.x, bv.y, bv.z, bv.w);
+					B.bl[jj] = make_uint4(bv.x, bv.y, bv.z, bv.w);
 				}
 			}
+		};
+		auto block_end = [&](const uint32_t (&gg)[8], const uint32_t (&fh)[8]) {
 			fc0 = fh[5]; fc1 = fh[6]; fc2 = fh[7];
 			sprev[7] = gg[7];
 #pragma unroll
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		 * this loop, 53.2 instead of 52.2 ms per 3e8 reads.) */
 		auto phase_c = [&](const BlockState &B, const int pos0) {
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
+			for (int j = 0; j < HB; ++j) {
 				const bool sel = __builtin_amdgcn_inverse_ballot_w64(B.sel[j]);
 				cur.x = sel ? B.bl[j].x : cur.x;
 				cur.y = sel ? B.bl[j].y : cur.y;
@@ -575,12 +588,18 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		};
 
 		BlockState S;
-		uint2 e8[8];
+		uint2 e[HB];
 #pragma unroll 1
 		for (int b = 0; b < NB; ++b) {
-			lut_reads(*reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr(t + 1, b * 8)), e8);
-			phase_a(e8, S);
-			phase_c(S, t * C + b * 8);
+			const uint2 v = *reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr<C>(t + 1, b * 8));
+			uint32_t gg[8], fh[8], pm = 0xFFFFFFFFu;
+#pragma unroll
+			for (int j0 = 0; j0 < 8; j0 += HB) {
+				lut_reads(v, j0, e);
+				phase_a(e, S, j0, gg, fh, pm);
+				phase_c(S, t * C + b * 8 + j0);
+			}
+			block_end(gg, fh);
 		}
 		drain(true);
 #undef NTSM_STEP
@@ -1143,6 +1162,10 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	const bool fast = plan.mode >= 0 && c->d_blocks && c->kernel_variant != 1;
 	p.fk_k = plan.k; p.fk_m2 = 2 * plan.m; p.fk_a2 = 2 * plan.a;
 	const bool tab = fast && !per_read && c->tab_ok && c->d_tblocks && c->kernel_variant == 3;
+	if (fast && !tab) {                                     /* the minimizer-blocked kernels cut the stream into their own tiles */
+		const uint64_t ftile = (uint64_t) kThreads * kFastC;
+		p.n_tiles = (hi - (uint64_t) p.t0 + ftile - 1) / ftile;
+	}
 	NtsmCountParams pt = p;                                 /* the tabulated kernel's view: 64 KiB tiles, segments of kTabSegTiles */
 	uint64_t tab_tiles = 0, tab_segs = 0;
 	ntsm_ctx::StreamBuf tab_sb = { nullptr, nullptr, 0, 0, nullptr, 0, { nullptr, nullptr }, { nullptr, nullptr } };
@@ -1260,17 +1283,17 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		/* whatever follows on the launch stream (the list walker, the timing event, the caller's sync) sees the look-ups done */
 		HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[(tab_segs - 1) & 1], 0));
 		if (tab_segs > 1) HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[tab_segs & 1], 0));
-		hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false>), dim3((unsigned) std::min<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles)), dim3(kThreads), 0, st, p);
+		hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kListC>), dim3((unsigned) std::min<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles)), dim3(kThreads), 0, st, p);
 		c->n_launch[0]++;
 	} else if (fast) {
 		const dim3 g((unsigned) grid), b(kThreads);
 		switch (plan.mode * 2 + (per_read ? 1 : 0)) {
-		case 0: hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false>), g, b, 0, st, p); break;
-		case 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<0, true>), g, b, 0, st, p); break;
-		case 2: hipLaunchKernelGGL((ntsm_count_mz_kernel<1, false>), g, b, 0, st, p); break;
-		case 3: hipLaunchKernelGGL((ntsm_count_mz_kernel<1, true>), g, b, 0, st, p); break;
-		case 4: hipLaunchKernelGGL((ntsm_count_mz_kernel<2, false>), g, b, 0, st, p); break;
-		default: hipLaunchKernelGGL((ntsm_count_mz_kernel<2, true>), g, b, 0, st, p); break;
+		case 0: hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kFastC>), g, b, 0, st, p); break;
+		case 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<0, true, kFastC>), g, b, 0, st, p); break;
+		case 2: hipLaunchKernelGGL((ntsm_count_mz_kernel<1, false, kFastC>), g, b, 0, st, p); break;
+		case 3: hipLaunchKernelGGL((ntsm_count_mz_kernel<1, true, kFastC>), g, b, 0, st, p); break;
+		case 4: hipLaunchKernelGGL((ntsm_count_mz_kernel<2, false, kFastC>), g, b, 0, st, p); break;
+		default: hipLaunchKernelGGL((ntsm_count_mz_kernel<2, true, kFastC>), g, b, 0, st, p); break;
 		}
 		c->n_launch[1]++;
 	}
