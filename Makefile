@@ -4,6 +4,7 @@
 #   build/ntsmCount           host CLI (C++), links libntsm_hip.so
 #   build/ntsm_synth          generator CLI
 #   build/ntsm_host_test      host-logic test driver (no GPU calls)
+#   ntsm_amd/libntsm_eval_hip.so, build/ntsmEval   all-pairs scoring of ntsmEval (HIP library + CLI mirror)
 #   oracle/                   CPU checker (+ oracle/_ref when /root/reference is present)
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
@@ -17,7 +18,7 @@ HOSTSRC  := $(HOST)/seq_reader.cpp $(HOST)/site_set.cpp $(HOST)/report.cpp $(HOS
             $(HOST)/inflate.cpp $(HOST)/gz_stream.cpp $(HOST)/crc32_fast.cpp
 HOSTHDR  := $(wildcard $(HOST)/*.hpp) include/ntsm_host.h include/ntsm_hip.h
 
-all: oracle_all build/ntsm_synth build/gather_bench ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount
+all: oracle_all build/ntsm_synth build/gather_bench ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount ntsm_amd/libntsm_eval_hip.so build/ntsmEval
 
 # host-only pieces (reader, site loader, report formatting): no HIP dependency
 ntsm_amd/libntsm_host.so: $(HOSTSRC) $(HOST)/host_capi.cpp $(HOSTHDR)
@@ -30,6 +31,15 @@ build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp 
 
 ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ntsm_hip.hip -ldl
+
+# ntsmEval all-pairs scoring: own library, own CLI
+ntsm_amd/libntsm_eval_hip.so: $(CSRC)/ntsm_eval.hip include/ntsm_eval_hip.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -shared -o $@ $(CSRC)/ntsm_eval.hip
+
+build/ntsmEval: $(HOST)/ntsm_eval_main.cpp include/ntsm_eval_hip.h ntsm_amd/libntsm_eval_hip.so
+	@mkdir -p build
+	$(CXX) $(CXXFLAGS) -ffp-contract=off -o $@ $(HOST)/ntsm_eval_main.cpp -Lntsm_amd -lntsm_eval_hip \
+	    -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
 # ablation builds of the tabulated kernel for tools/ab_libs.sh (never shipped: wrong counts by construction)
 ablation: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h

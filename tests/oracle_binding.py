@@ -114,3 +114,75 @@ class OracleFP:
             self.close()
         except Exception:
             pass
+
+
+# ---- ntsmEval all-pairs scoring (oracle/ntsm_eval_oracle.c; parity with the reference unpinned) ---------------
+_elib = None
+
+
+class EvalPair(C.Structure):
+    _fields_ = [("sum_joint", C.c_double), ("sum_single1", C.c_double), ("sum_single2", C.c_double), ("n_valid", C.c_uint64),
+                ("hets1", C.c_uint32), ("homs1", C.c_uint32), ("hets2", C.c_uint32), ("homs2", C.c_uint32),
+                ("shared_hets", C.c_uint32), ("shared_homs", C.c_uint32), ("ibs0", C.c_uint32), ("ibs2", C.c_uint32)]
+
+
+def eval_lib():
+    global _elib
+    if _elib is None:
+        path = os.path.join(ROOT, "oracle", "libntsm_eval_oracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libntsm_eval_oracle.so", "ntsm_eval_oracle"], check=True)
+        L = C.CDLL(path)
+        L.ntsm_eval_oracle_load.restype = C.c_void_p
+        L.ntsm_eval_oracle_load.argtypes = [C.POINTER(C.c_char_p), C.c_uint]
+        L.ntsm_eval_oracle_free.argtypes = [C.c_void_p]
+        for f in ("samples", "sites"):
+            fn = getattr(L, "ntsm_eval_oracle_" + f); fn.restype = C.c_uint; fn.argtypes = [C.c_void_p]
+        for f in ("counts", "sums", "distinct"):
+            fn = getattr(L, "ntsm_eval_oracle_" + f); fn.restype = C.POINTER(C.c_uint); fn.argtypes = [C.c_void_p]
+        for f in ("total", "raw_total"):
+            fn = getattr(L, "ntsm_eval_oracle_" + f); fn.restype = C.c_uint64; fn.argtypes = [C.c_void_p, C.c_uint]
+        L.ntsm_eval_oracle_kmer_size.restype = C.c_uint
+        L.ntsm_eval_oracle_kmer_size.argtypes = [C.c_void_p, C.c_uint]
+        L.ntsm_eval_oracle_genotype.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint)]
+        L.ntsm_eval_oracle_error_rate.restype = C.c_double
+        L.ntsm_eval_oracle_error_rate.argtypes = [C.c_void_p, C.c_uint, C.c_uint64]
+        L.ntsm_eval_oracle_pair.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.POINTER(EvalPair)]
+        L.ntsm_eval_oracle_score.restype = C.c_double
+        L.ntsm_eval_oracle_score.argtypes = [C.POINTER(EvalPair), C.c_double, C.c_double, C.c_double]
+        _elib = L
+    return _elib
+
+
+class EvalOracle:
+    """ntsm_eval_oracle wrapper: CompareCounts on the CPU (counts files in, per-pair records out)."""
+
+    def __init__(self, files):
+        self.L = eval_lib()
+        arr = (C.c_char_p * len(files))(*[os.fsencode(f) for f in files])
+        self.h = self.L.ntsm_eval_oracle_load(arr, len(files))
+        assert self.h, files
+        self.n, self.m = self.L.ntsm_eval_oracle_samples(self.h), self.L.ntsm_eval_oracle_sites(self.h)
+
+    def counts(self):
+        p = self.L.ntsm_eval_oracle_counts(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.n, self.m, 2)).copy()
+
+    def pair(self, i, j, min_cov=1):
+        r = EvalPair()
+        self.L.ntsm_eval_oracle_pair(self.h, i, j, min_cov, C.byref(r))
+        return r
+
+    def genotype(self, i, min_cov=1):
+        out = (C.c_uint * 3)()
+        self.L.ntsm_eval_oracle_genotype(self.h, i, min_cov, out)
+        return tuple(out)                                  # hets, homs, miss
+
+    def close(self):
+        if self.h:
+            self.L.ntsm_eval_oracle_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
