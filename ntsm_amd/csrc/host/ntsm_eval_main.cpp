@@ -2,8 +2,8 @@
  * ntsm_eval_main.cpp -- host mirror of the reference's ntsmEval for its all-to-all path (src/ntSeqMatchEval.cpp:86-349,
  * src/CompareCounts.hpp): same flags, same stdout bytes; the pair loop of CompareCounts::computeScore (:591-624) is one
  * call into the HIP library (include/ntsm_eval_hip.h).  A single input file prints the QC table (computeScoreSingle,
- * :541-585) without touching the GPU.  Not built: the PCA / kd-tree search (-p, -n and its radii) and merging (-e, -o);
- * asking for them is an error instead of a silent all-to-all run.  Parity with the reference is unpinned (DESIGN.md
+ * :541-585) without touching the GPU; -e FILE writes the merged counts (mergeCounts, :626-674), -o skips the analysis.
+ * Not built: the PCA / kd-tree search (-p, -n and its radii); asking for it is an error instead of a silent all-to-all run.  Parity with the reference is unpinned (DESIGN.md
  * section 9): the reference's scoring class cannot be compiled in this image.
  */
 #include <getopt.h>
@@ -153,7 +153,10 @@ void printHelpDialog()
 	    "  -G, --gpu = INT            HIP device [0] (this build only)\n"
 	    "  -h, --help                 Display this dialog.\n"
 	    "  -v, --verbose              Display verbose output.\n"
-	    "Not in this build: -p/-n/-d/-r/-1/-2/-S/-l (PCA search), -e/-o (merge).\n" << std::endl;
+	    "  -e, --merge = STR          After analysis merge counts and output to file.\n"
+	    "  -o, --only_merge           Do not perform an analysis. Only functions when\n"
+	    "                             -e (--merge) option is specified.\n"
+	    "Not in this build: -p/-n/-d/-r/-1/-2/-S/-l (PCA search).\n" << std::endl;
 	exit(EXIT_SUCCESS);
 }
 
@@ -199,8 +202,8 @@ int main(int argc, char **argv)
 			abort();
 		}
 	if (c.files.empty()) { std::cerr << "Error: Need Input File" << std::endl; die = true; }
-	if (!opt.pca.empty() || !opt.merge.empty() || opt.onlyMerge) {
-		std::cerr << "Error: the PCA search (-p) and merging (-e, -o) are not part of this build" << std::endl;
+	if (!opt.pca.empty()) {
+		std::cerr << "Error: the PCA search (-p) is not part of this build" << std::endl;
 		die = true;
 	}
 	if (die) { std::cerr << "Try '--help' for more information.\n"; exit(EXIT_FAILURE); }
@@ -213,6 +216,10 @@ int main(int argc, char **argv)
 		std::cout << "sample\tcov\terrorRate\tmiss\thom\thet" << std::endl;
 		std::cout << c.files[0] << "\t" << std::to_string(g[0].cov) << "\t" << std::to_string(g[0].errorRate) << "\t" << std::to_string(g[0].miss)
 		          << "\t" << std::to_string(g[0].homs) << "\t" << std::to_string(g[0].hets);
+	} else if (opt.onlyMerge) {                          /* src/ntSeqMatchEval.cpp:314-322 */
+		if (opt.verbose > 1) std::cerr << "Finished loading files. Now comparing all samples." << std::endl;
+		if (opt.merge.empty()) { std::cerr << "(-l) cannot be used without --merge (-e) option." << std::endl; exit(EXIT_FAILURE); }
+		std::cerr << " (-l) option detected. Not performing analysis, only merging." << std::endl;
 	} else {                                             /* computeScore, :591-624 */
 		if (opt.verbose > 1) std::cerr << "Finished loading files. Now comparing all samples." << std::endl;
 		std::cerr << "Performing all-to-all score computation.\nSpecify -p (--pca) to enable faster comparisons." << std::endl;
@@ -257,6 +264,25 @@ int main(int argc, char **argv)
 			}
 	}
 	std::cout.flush();
+	if (c.files.size() > 1 && !opt.merge.empty()) {      /* mergeCounts, :626-674 */
+		for (size_t i = 0; i < c.kmerSize.size(); ++i)
+			for (size_t j = i + 1; j < c.kmerSize.size(); ++j)
+				if (c.kmerSize[i] != c.kmerSize[j]) { std::cerr << PROGRAM ": counts files with different k cannot be merged" << std::endl; abort(); }   /* assert, :631-635 */
+		std::ofstream out(opt.merge);
+		uint64_t tk = 0;
+		for (uint64_t v : c.rawTotal) tk += v;
+		out << "#@TK\t" << std::to_string(tk) << "\n#@KS\t" << std::to_string(c.kmerSize[0])
+		    << "\n#locusID\tcountAT\tcountCG\tsumAT\tsumCG\tdistinctAT\tdistinctCG\n";
+		const size_t m = c.nSites();
+		for (size_t s = 0; s < m; ++s) {
+			unsigned cAT = 0, cCG = 0, sAT = 0, sCG = 0;
+			for (size_t j = 0; j < c.files.size(); ++j) {
+				cAT += c.counts[(j * m + s) * 2]; cCG += c.counts[(j * m + s) * 2 + 1];
+				sAT += c.sums[(j * m + s) * 2]; sCG += c.sums[(j * m + s) * 2 + 1];
+			}
+			out << c.locus[s] << "\t" << cAT << "\t" << cCG << "\t" << sAT << "\t" << sCG << "\t" << c.distinct[2 * s] << "\t" << c.distinct[2 * s + 1] << "\n";
+		}
+	}
 	std::cerr << "Time: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
 	return 0;
 }

@@ -16,7 +16,7 @@
  * computeScore (:591-624, one thread: pairs in i < j order), calcHomHetMiss (:742-767), loadPair (:934-940),
  * computeSumLogPSingle (:968-989), computeSumLogPJoint (:1013-1033), gatherValidEntries (:1057-1078),
  * skew (:1081-1083), computeLogLikelihood (:1093-1099), calcRelatedness (:1144-1196), computeErrorRate
- * (:1198-1216), resultsStr (:843-905).  Not covered: PCA projection and kd-tree search (-p), merge (-e).
+ * (:1198-1216), resultsStr (:843-905), mergeCounts (:626-674).  Not covered: PCA projection and kd-tree search (-p).
  */
 #define _GNU_SOURCE
 #include "ntsm_eval_oracle.h"
@@ -354,5 +354,27 @@ int ntsm_eval_oracle_print(const ntsm_eval_oracle *e, FILE *out, unsigned min_co
 			}
 	}
 	free(geno); free(err); free(cov);
+	return 0;
+}
+
+/* mergeCounts (:626-674): tags summed / taken from the first file, per locus the 32-bit sums of counts and sums over all
+ * files, the first file's distinct columns.  Returns -1 where the reference's assert on unequal k fails. */
+int ntsm_eval_oracle_merge(const ntsm_eval_oracle *e, FILE *out)
+{
+	for (unsigned i = 0; i < e->n_samples; ++i)
+		for (unsigned j = i + 1; j < e->n_samples; ++j)
+			if (e->kmer_size[i] != e->kmer_size[j]) return -1;
+	uint64_t tk = 0;
+	for (unsigned i = 0; i < e->n_samples; ++i) tk += e->raw_total[i];
+	fprintf(out, "#@TK\t%llu\n#@KS\t%u\n#locusID\tcountAT\tcountCG\tsumAT\tsumCG\tdistinctAT\tdistinctCG\n", (unsigned long long) tk, e->kmer_size[0]);
+	for (unsigned s = 0; s < e->n_sites; ++s) {
+		unsigned cAT = 0, cCG = 0, sAT = 0, sCG = 0;
+		for (unsigned j = 0; j < e->n_samples; ++j) {
+			const size_t at = ((size_t) j * e->n_sites + s) * 2;
+			cAT += e->counts[at]; cCG += e->counts[at + 1];
+			sAT += e->sums[at]; sCG += e->sums[at + 1];
+		}
+		fprintf(out, "%s\t%u\t%u\t%u\t%u\t%u\t%u\n", e->locus[s], cAT, cCG, sAT, sCG, e->distinct[2 * s], e->distinct[2 * s + 1]);
+	}
 	return 0;
 }

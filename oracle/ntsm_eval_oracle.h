@@ -34,6 +34,7 @@ void ntsm_eval_oracle_genotype(const ntsm_eval_oracle *e, unsigned i, unsigned m
 double ntsm_eval_oracle_error_rate(const ntsm_eval_oracle *e, unsigned i, uint64_t genome_size);
 void ntsm_eval_oracle_pair(const ntsm_eval_oracle *e, unsigned i1, unsigned i2, unsigned min_cov, ntsm_eval_pair *r);
 double ntsm_eval_oracle_score(const ntsm_eval_pair *r, double cov1, double cov2, double cov_skew);
+int ntsm_eval_oracle_merge(const ntsm_eval_oracle *e, FILE *out);       /* mergeCounts; -1: samples with different k */
 int ntsm_eval_oracle_print(const ntsm_eval_oracle *e, FILE *out, unsigned min_cov, double score_thresh, int all, double cov_skew, uint64_t genome_size);
 
 #ifdef __cplusplus

@@ -181,6 +181,15 @@ def test_eval_library_exports_and_cli_without_gpu(tmp_path):
     assert p.returncode == 0 and b"Error - Invalid parameter s: abc" in p.stderr and p.stdout == b""   # message + return 0, like ntsmCount's main
     p = run("-p", "rot.tsv", one, one)
     assert p.returncode == 1 and b"not part of this build" in p.stderr
+    # merge only (-e FILE -o: mergeCounts, :626-674; no GPU involved): bytes of the merged file against the oracle's
+    parts = files_for(tmp_path, random_samples(rng, 3, 40), tk=1000)
+    mine, ref = str(tmp_path / "merged.txt"), str(tmp_path / "merged_ref.txt")
+    p = run("-e", mine, "-o", *parts)
+    q = subprocess.run([ORACLE_CLI, "-e", ref, "-o"] + parts, capture_output=True)
+    assert p.returncode == 0 and q.returncode == 0 and p.stdout == b"" and q.stdout == b""
+    assert open(mine, "rb").read() == open(ref, "rb").read() and open(mine).readline() == "#@TK\t3000\n"
+    p = run("-o", *parts)
+    assert p.returncode == 1 and b"cannot be used without --merge" in p.stderr
     p = run(str(tmp_path / "nope.txt"))
     assert p.returncode < 0 or p.returncode == 134                           # abort()
     p = run("-c", "2", "-g", "3100000000", one)
