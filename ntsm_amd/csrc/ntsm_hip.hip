@@ -273,14 +273,15 @@ __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
 }
 
 /* KMODE 0: k = 19 with every constant folded (the reference default and all BASELINE configurations).
- * KMODE 1 / 2: any other k of ntsm_fast_plan(), 8 / 9 minimizer candidates; k, the minimizer length and the
- * candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each). */
+ * KMODE 4 .. 9: any other k of ntsm_fast_plan(), KMODE = number of minimizer candidates; k, the minimizer length and
+ * the candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each). */
 template <int KMODE, bool PER_READ, int C>
 __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_mz_kernel(const NtsmCountParams p)
 {
 	constexpr int VPT = C / 16, NB = C / 8, HB = NTSM_STEP_POS;
 	constexpr bool GEN = KMODE != 0;
-	constexpr int W = KMODE == 0 ? NTSM_FAST_W : (KMODE == 1 ? 8 : 9);
+	constexpr int W = KMODE == 0 ? NTSM_FAST_W : KMODE;
+	static_assert(W >= 4 && W <= 9, "sliding minimum: 4 .. 9 candidates");
 	const uint32_t gk = GEN ? p.fk_k : (uint32_t) NTSM_FAST_K;            /* wave-uniform run-time k of the general kernels */
 	const uint32_t g_a2 = p.fk_a2, g_mmask = (1u << p.fk_m2) - 1u, g_rsh = 64u - p.fk_m2 - p.fk_a2, g_fsh = 64u - 2u * gk;
 	const uint32_t g_rmask = gk >= 16 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (32u - 2u * gk);
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		 * the current R (its last 16, reversed); the window is valid when run > 19. */
 		uint32_t F = 0, R = 0, run = 1;
 		uint32_t Fh = 0, Ro = 0;                            /* general k: bases 17..32 back of the forward word, of the reverse word */
-		uint32_t sprev[8];                                  /* suffix minima of the previous 8-block, [1..7] used */
+		uint32_t sprev[8];                                  /* W >= 8: suffix minima of the previous 8-block, [1..7] used */
+		uint32_t gprev[8], m2prev[8];                       /* W < 8: order hashes of the previous 8-block ([2..7] used) and their pair minima ([4..7]) */
 		uint32_t fc0 = 0, fc1 = 0, fc2 = 0;                 /* k = 19: F at the three positions before the current block */
 		uint32_t qn = 0;                                    /* wave-uniform queue fill */
 #define NTSM_STEP(e_)                                                                     \
@@ -378,12 +380,19 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				const uint2 e = lut64[(w[i >> 2] >> ((i & 3) * 8)) & 0xFFu];
 				NTSM_STEP(e)
 				fh[i] = F;
-				if (i >= 24 + (9 - W)) gw[i - 24] = NTSM_MMER_G();   /* the last W-1 positions of the previous 8-block */
+				if (i >= 24 + (W >= 8 ? 9 - W : 1)) gw[i - 24] = NTSM_MMER_G();   /* the last positions of the previous 8-block */
 			}
 			fc0 = fh[29]; fc1 = fh[30]; fc2 = fh[31];
-			sprev[7] = gw[7];
+			if (W >= 8) {
+				sprev[7] = gw[7];
 #pragma unroll
-			for (int i = 6; i >= 9 - W; --i) sprev[i] = min(gw[i], sprev[i + 1]);
+				for (int i = 6; i >= 9 - W; --i) sprev[i] = min(gw[i], sprev[i + 1]);
+			} else {
+#pragma unroll
+				for (int i = 1; i < 8; ++i) gprev[i] = gw[i];
+#pragma unroll
+				for (int i = 2; i < 8; ++i) m2prev[i] = min(gw[i], gw[i - 1]);
+			}
 		}
 		uint32_t mz_prev = 0;
 		uint4 cur = make_uint4(0, 0, 0, 0);                  /* the lane's cached 128-bit filter block */
@@ -512,16 +521,28 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #pragma unroll
 			for (int jj = 0; jj < HB; ++jj) { const int j = j0 + jj; e[jj] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu]; }
 		};
-		/* gg / fh / pm: order hashes, forward words and prefix minimum of the current 8-block (they outlive a 4-position step) */
-		auto phase_a = [&](const uint2 (&e)[HB], BlockState &B, const int j0, uint32_t (&gg)[8], uint32_t (&fh)[8], uint32_t &pm) {
+		/* gg / fh / pm: order hashes, forward words and prefix minimum of the current 8-block (they outlive a 4-position step);
+		 * m2: minima of adjacent pairs (W < 8) */
+		auto phase_a = [&](const uint2 (&e)[HB], BlockState &B, const int j0, uint32_t (&gg)[8], uint32_t (&fh)[8], uint32_t &pm, uint32_t (&m2)[8]) {
 #pragma unroll
 			for (int jj = 0; jj < HB; ++jj) {
 				const int j = j0 + jj;
 				NTSM_STEP(e[jj])
 				fh[j] = F;
 				gg[j] = NTSM_MMER_G();
-				pm = min(pm, gg[j]);
-				const uint32_t mz = j + 9 - W <= 7 ? min(sprev[j + 9 - W], pm) : pm;
+				uint32_t mz;
+				if (W >= 8) {
+					pm = min(pm, gg[j]);
+					mz = j + 9 - W <= 7 ? min(sprev[j + 9 - W], pm) : pm;
+				} else {
+					/* fewer than 8 candidates: minimum of the last W order hashes by doubling -- pairs, fours, then what is
+					 * left of W (negative indices: the previous 8-block) */
+					auto G = [&](int q) { return q >= 0 ? gg[q] : gprev[q + 8]; };
+					auto M2 = [&](int q) { return q >= 0 ? m2[q] : m2prev[q + 8]; };
+					m2[j] = min(gg[j], G(j - 1));
+					const uint32_t m4 = min(m2[j], M2(j - 2));
+					mz = W == 4 ? m4 : W == 5 ? min(m4, G(j - 4)) : W == 6 ? min(m4, M2(j - 4)) : min(m4, min(M2(j - 4), G(j - 6)));
+				}
 				B.f3[jj] = GEN ? f_top() : (j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)));
 				B.r[jj] = GEN ? (R & g_rmask) : R;
 				B.u[jj] = ntsm_kmer_sum(B.f3[jj], B.r[jj]);
@@ -547,11 +568,18 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				}
 			}
 		};
-		auto block_end = [&](const uint32_t (&gg)[8], const uint32_t (&fh)[8]) {
+		auto block_end = [&](const uint32_t (&gg)[8], const uint32_t (&fh)[8], const uint32_t (&m2)[8]) {
 			fc0 = fh[5]; fc1 = fh[6]; fc2 = fh[7];
-			sprev[7] = gg[7];
+			if (W >= 8) {
+				sprev[7] = gg[7];
 #pragma unroll
-			for (int j = 6; j >= 9 - W; --j) sprev[j] = min(gg[j], sprev[j + 1]);
+				for (int j = 6; j >= 9 - W; --j) sprev[j] = min(gg[j], sprev[j + 1]);
+			} else {
+#pragma unroll
+				for (int j = 2; j < 8; ++j) gprev[j] = gg[j];
+#pragma unroll
+				for (int j = 4; j < 8; ++j) m2prev[j] = m2[j];
+			}
 		};
 		/* Phase C: four-bit test against the (possibly just fetched) block.  word << field (NTSM_KBITn: bit 31 - field)
 		 * puts the tested bit in the sign position -- the shifter takes the low five bits of the selected byte, so the
@@ -592,14 +620,14 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #pragma unroll 1
 		for (int b = 0; b < NB; ++b) {
 			const uint2 v = *reinterpret_cast<const uint2 *>(tile + ntsm_tile_addr<C>(t + 1, b * 8));
-			uint32_t gg[8], fh[8], pm = 0xFFFFFFFFu;
+			uint32_t gg[8], fh[8], m2[8], pm = 0xFFFFFFFFu;
 #pragma unroll
 			for (int j0 = 0; j0 < 8; j0 += HB) {
 				lut_reads(v, j0, e);
-				phase_a(e, S, j0, gg, fh, pm);
+				phase_a(e, S, j0, gg, fh, pm, m2);
 				phase_c(S, t * C + b * 8 + j0);
 			}
-			block_end(gg, fh);
+			block_end(gg, fh, m2);
 		}
 		drain(true);
 #undef NTSM_STEP
@@ -1287,14 +1315,14 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		c->n_launch[0]++;
 	} else if (fast) {
 		const dim3 g((unsigned) grid), b(kThreads);
+#define NTSM_MZ_CASE(M_) \
+		case 2 * M_: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, false, kFastC>), g, b, 0, st, p); break; \
+		case 2 * M_ + 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, true, kFastC>), g, b, 0, st, p); break;
 		switch (plan.mode * 2 + (per_read ? 1 : 0)) {
-		case 0: hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kFastC>), g, b, 0, st, p); break;
-		case 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<0, true, kFastC>), g, b, 0, st, p); break;
-		case 2: hipLaunchKernelGGL((ntsm_count_mz_kernel<1, false, kFastC>), g, b, 0, st, p); break;
-		case 3: hipLaunchKernelGGL((ntsm_count_mz_kernel<1, true, kFastC>), g, b, 0, st, p); break;
-		case 4: hipLaunchKernelGGL((ntsm_count_mz_kernel<2, false, kFastC>), g, b, 0, st, p); break;
-		default: hipLaunchKernelGGL((ntsm_count_mz_kernel<2, true, kFastC>), g, b, 0, st, p); break;
+		NTSM_MZ_CASE(0) NTSM_MZ_CASE(4) NTSM_MZ_CASE(5) NTSM_MZ_CASE(6) NTSM_MZ_CASE(7) NTSM_MZ_CASE(8) NTSM_MZ_CASE(9)
+		default: return NTSM_ERR_STATE;
 		}
+#undef NTSM_MZ_CASE
 		c->n_launch[1]++;
 	}
 	else if (per_read) {
