@@ -158,7 +158,7 @@ int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
 /* Tuning knobs (0 = automatic): log2 of filter bits (rebuilds the tables: counts and totals restart from zero),
  * grid blocks.  For profiling experiments. */
 int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
-/* Kernel choice: 0 = automatic (15 <= k <= 31: the minimizer-blocked kernel; other k: the generic kernel), 1 = always the
+/* Kernel choice: 0 = automatic (13 <= k <= 31: the minimizer-blocked kernel; other k: the generic kernel), 1 = always the
  * generic kernel, 2 = same as 0, 3 = k == 19 only: the tabulated kernel (table-driven hashes, 2-bit packed tiles, look-up
  * kernel on a second stream; the minimizer-blocked kernel still takes tiles that hold bytes outside ACGTUNacgtun and -m
  * batches).  All give identical results; 3 is measured 7 % slower than 0 on the bench workload. */

@@ -49,19 +49,19 @@ NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC
 #define NTSM_FAST_W (NTSM_FAST_K - NTSM_FAST_M + 1)
 #define NTSM_MMER_MASK ((1u << (2 * NTSM_FAST_M)) - 1u)
 
-/* The same filter for other k (15 <= k <= 31, k != 19): 12-mers throughout; what varies is which of them are minimizer
+/* The same filter for other k (13 <= k <= 31, k != 19): 12-mers throughout; what varies is which of them are minimizer
  * candidates.  The candidate set must map onto itself under reverse complement, i.e. be symmetric in the k-mer:
  *   k >= 19   the 8 (k odd) or 9 (k even) innermost 12-mers: offsets a .. a + w - 1 from either end,
  *             a = (k - 12 - (w - 1)) / 2  (k = 19: all 8, a = 0)
- *   k <  19   all k - 11 of them (4 .. 7)
- * so the sliding minimum runs over 4 .. 9 order hashes, computed `a` positions behind the newest base. */
+ *   k <  19   all k - 11 of them (2 .. 7)
+ * so the sliding minimum runs over 2 .. 9 order hashes, computed `a` positions behind the newest base. */
 struct NtsmFastPlan { int mode; uint32_t k, m, w, a; };      /* mode: -1 no fast path, 0 the k = 19 kernel, else w (the kernel's KMODE) */
 NTSM_DHD NtsmFastPlan ntsm_fast_plan(uint32_t k)
 {
 	NtsmFastPlan pl = { -1, k, 0u, 0u, 0u };
 	if (k == NTSM_FAST_K) { pl.mode = 0; pl.m = NTSM_FAST_M; pl.w = NTSM_FAST_W; }
 	else if (k >= 19 && k <= 31) { pl.m = 12; pl.w = (k & 1u) ? 8u : 9u; pl.a = (k - 12u - (pl.w - 1u)) / 2u; pl.mode = (int) pl.w; }
-	else if (k >= 15 && k < 19) { pl.m = 12; pl.w = k - 11u; pl.mode = (int) pl.w; }
+	else if (k >= 13 && k < 19) { pl.m = 12; pl.w = k - 11u; pl.mode = (int) pl.w; }
 	return pl;
 }
 /* the two 32-bit words whose sum picks the filter bits: the k-mer's forward and reverse-complement codes, left-aligned

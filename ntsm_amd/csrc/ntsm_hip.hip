@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(
 }
 
 /* --------------------------------------------------------------------------------------------
- * Minimizer-blocked fast path: k = 19 with every constant folded, and 15 <= k <= 31
+ * Minimizer-blocked fast path: k = 19 with every constant folded, and 13 <= k <= 31
  * with k as a run-time parameter (ntsm_fast_plan, ntsm_device.h).  Same tiling as the generic kernel; per
  * position a lane
  *   1. rolls the forward / reverse-complement words, the run of valid bases and the canonical m-mer order hash,
@@ -273,7 +273,7 @@ __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
 }
 
 /* KMODE 0: k = 19 with every constant folded (the reference default and all BASELINE configurations).
- * KMODE 4 .. 9: any other k of ntsm_fast_plan(), KMODE = number of minimizer candidates; k, the minimizer length and
+ * KMODE 2 .. 9: any other k of ntsm_fast_plan(), KMODE = number of minimizer candidates; k, the minimizer length and
  * the candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each). */
 template <int KMODE, bool PER_READ, int C>
 __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_mz_kernel(const NtsmCountParams p)
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 	constexpr int VPT = C / 16, NB = C / 8, HB = NTSM_STEP_POS;
 	constexpr bool GEN = KMODE != 0;
 	constexpr int W = KMODE == 0 ? NTSM_FAST_W : KMODE;
-	static_assert(W >= 4 && W <= 9, "sliding minimum: 4 .. 9 candidates");
+	static_assert(W >= 2 && W <= 9, "sliding minimum: 2 .. 9 candidates");
 	const uint32_t gk = GEN ? p.fk_k : (uint32_t) NTSM_FAST_K;            /* wave-uniform run-time k of the general kernels */
 	const uint32_t g_a2 = p.fk_a2, g_mmask = (1u << p.fk_m2) - 1u, g_rsh = 64u - p.fk_m2 - p.fk_a2, g_fsh = 64u - 2u * gk;
 	const uint32_t g_rmask = gk >= 16 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (32u - 2u * gk);
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 					auto M2 = [&](int q) { return q >= 0 ? m2[q] : m2prev[q + 8]; };
 					m2[j] = min(gg[j], G(j - 1));
 					const uint32_t m4 = min(m2[j], M2(j - 2));
-					mz = W == 4 ? m4 : W == 5 ? min(m4, G(j - 4)) : W == 6 ? min(m4, M2(j - 4)) : min(m4, min(M2(j - 4), G(j - 6)));
+					mz = W == 2 ? m2[j] : W == 3 ? min(m2[j], G(j - 2)) : W == 4 ? m4 : W == 5 ? min(m4, G(j - 4)) : W == 6 ? min(m4, M2(j - 4)) : min(m4, min(M2(j - 4), G(j - 6)));
 				}
 				B.f3[jj] = GEN ? f_top() : (j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2)));
 				B.r[jj] = GEN ? (R & g_rmask) : R;
@@ -1319,7 +1319,7 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		case 2 * M_: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, false, kFastC>), g, b, 0, st, p); break; \
 		case 2 * M_ + 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, true, kFastC>), g, b, 0, st, p); break;
 		switch (plan.mode * 2 + (per_read ? 1 : 0)) {
-		NTSM_MZ_CASE(0) NTSM_MZ_CASE(4) NTSM_MZ_CASE(5) NTSM_MZ_CASE(6) NTSM_MZ_CASE(7) NTSM_MZ_CASE(8) NTSM_MZ_CASE(9)
+		NTSM_MZ_CASE(0) NTSM_MZ_CASE(2) NTSM_MZ_CASE(3) NTSM_MZ_CASE(4) NTSM_MZ_CASE(5) NTSM_MZ_CASE(6) NTSM_MZ_CASE(7) NTSM_MZ_CASE(8) NTSM_MZ_CASE(9)
 		default: return NTSM_ERR_STATE;
 		}
 #undef NTSM_MZ_CASE

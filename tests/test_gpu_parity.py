@@ -247,12 +247,12 @@ def test_other_k_random_vs_oracle(nt, tmp_path):
 
 
 def test_minimizer_fast_path_every_k(nt, tmp_path):
-    """Every k the minimizer-blocked kernel takes besides 19 (15..31, ntsm_fast_plan in ntsm_device.h: 8 or 9 candidate
+    """Every k the minimizer-blocked kernel takes besides 19 (13..31, ntsm_fast_plan in ntsm_device.h: 8 or 9 candidate
     m-mers, candidate offset, 64-bit rolling words) against the oracle and against the generic kernel on the same input:
     random sites, reads cut from them with substitutions, N, lower case and junk, read lengths around k; the launch
     counters show which kernel ran.  Also the per-read (-m) instantiation: a threshold that trips mid-stream."""
     rng = np.random.default_rng(77)
-    for k in range(15, 32):
+    for k in range(13, 32):
         path = str(tmp_path / ("s%d.fa" % k))
         seqs = ["".join(rng.choice(list("ACGT"), size=2 * k + 9)) for _ in range(300)]
         with open(path, "w") as f:
