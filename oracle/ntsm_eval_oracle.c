@@ -10,7 +10,9 @@
  * reference ships neither that file, nor tests, nor recorded outputs for this path.  What is here follows
  * the reference text function by function (file:line cited at each), in the same order of floating-point
  * operations (sequential double sums over the sites in file order, no contraction), but it has never been
- * compared with the reference's own output.
+ * compared with the reference's own output -- except for the genotype tallies and the two ratios derived from them,
+ * which tests/test_eval.py checks against the six example rows of the reference's README (README.md:143-150); the
+ * log-likelihood score has no such anchor.
  *
  * Covered: CompareCounts::CompareCounts (:30-114), computeScoreSingle (:541-585, without PCA columns),
  * computeScore (:591-624, one thread: pairs in i < j order), calcHomHetMiss (:742-767), loadPair (:934-940),

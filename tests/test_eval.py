@@ -198,6 +198,56 @@ def test_eval_library_exports_and_cli_without_gpu(tmp_path):
     assert not p.stdout.endswith(b"\n")                                      # computeScoreSingle prints the row without a newline (:579-582)
 
 
+def readme_pairs(tmp_path):
+    """Two counts files per row of tests/golden/eval_readme_rows.json whose genotype categories reproduce the row's tallies:
+    het = (10, 10), hom AT = (20, 0), hom CG = (0, 20), missing = (0, 0) over 96287 sites."""
+    import json
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "eval_readme_rows.json")))
+    out = []
+    for k, row in enumerate(doc["rows"]):
+        r = dict(zip(doc["columns"], row))
+        HH, Hh, hH, SS, OO = r["sharedHet"], r["het1"] - r["sharedHet"], r["het2"] - r["sharedHet"], r["sharedHom"], r["ibs0"]
+        assert r["hom1"] == hH + SS + OO and r["hom2"] == Hh + SS + OO and r["n"] == HH + Hh + hH + SS + OO and r["ibs2"] == HH + SS
+        e_hom1, e_het1 = r["allHom1"] - r["hom1"], r["allHet1"] - r["het1"]     # sample 1 covered, sample 2 missing
+        e_hom2, e_het2 = r["allHom2"] - r["hom2"], r["allHet2"] - r["het2"]
+        both = 96287 - r["n"] - (e_hom1 + e_het1 + e_hom2 + e_het2)
+        assert both >= 0 and r["miss1"] == e_hom2 + e_het2 + both and r["miss2"] == e_hom1 + e_het1 + both
+        het, at, cg, no = (10, 10), (20, 0), (0, 20), (0, 0)
+        cats = [(HH, het, het), (Hh, het, at), (hH, cg, het), (SS, at, at), (OO, at, cg), (e_hom1, cg, no), (e_het1, het, no),
+                (e_hom2, no, at), (e_het2, no, het), (both, no, no)]
+        a = np.concatenate([np.tile(np.array(x, dtype=np.uint32), (c, 1)) for c, x, _ in cats if c])
+        b = np.concatenate([np.tile(np.array(y, dtype=np.uint32), (c, 1)) for c, _, y in cats if c])
+        assert a.shape == (96287, 2)
+        fa, fb = str(tmp_path / ("readme%d_a.txt" % k)), str(tmp_path / ("readme%d_b.txt" % k))
+        write_counts(fa, a); write_counts(fb, b)
+        out.append((fa, fb, r))
+    return out
+
+
+def check_against_readme(stdout, r):
+    lines = stdout.decode().split("\n")
+    head, vals = lines[0].split("\t"), lines[1].split("\t")
+    got = dict(zip(head, vals))
+    for col, key in (("relate", "relate"), ("homConcord", "homConcord")):
+        assert round(float(got[col]), 6) == float(r[key]), (col, got[col], r[key])
+    for col, key in (("ibs0", "ibs0"), ("ibs2", "ibs2"), ("het1", "het1"), ("het2", "het2"), ("sharedHet", "sharedHet"), ("hom1", "hom1"), ("hom2", "hom2"),
+                     ("sharedHom", "sharedHom"), ("n", "n"), ("miss1", "miss1"), ("miss2", "miss2"), ("allHom1", "allHom1"), ("allHom2", "allHom2"),
+                     ("allHet1", "allHet1"), ("allHet2", "allHet2")):
+        assert int(got[col]) == r[key], (col, got[col], r[key])
+
+
+def test_oracle_reproduces_the_readme_example_rows(tmp_path):
+    """The one recorded output the reference holds for ntsmEval: the six example rows of its README (README.md:143-150,
+    tests/golden/eval_readme_rows.json).  Their input files are not in the checkout, but the tallies of a row determine the
+    genotype categories of the two samples, so inputs with exactly those categories must give back the row's tallies, its
+    'relate' and 'homConcord' (to the printed six decimals), missing / hom / het totals and n.  This pins calcRelatedness,
+    calcHomHetMiss, gatherValidEntries and the two ratios to the reference's own numbers; the score column stays unpinned."""
+    for fa, fb, r in readme_pairs(tmp_path):
+        q = subprocess.run([ORACLE_CLI, "-a", fa, fb], capture_output=True)
+        assert q.returncode == 0
+        check_against_readme(q.stdout, r)
+
+
 # ---------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 def test_hip_pairs_equal_oracle_bit_for_bit(tmp_path):
@@ -244,6 +294,8 @@ def test_cli_equals_oracle_cli_bytes(tmp_path):
         assert p.stdout == q.stdout and p.stdout.count(b"\n") >= 1, args
     a = subprocess.run([EVAL, "-a"] + files, capture_output=True).stdout
     assert a.count(b"\n") == 1 + 12 * 11 // 2
+    for fa, fb, r in readme_pairs(tmp_path)[:3]:                             # the reference's README example rows through the GPU path
+        check_against_readme(subprocess.run([EVAL, "-a", fa, fb], capture_output=True).stdout, r)
     # counts files from the counting CLI itself
     sp = str(tmp_path / "sites.fa")
     s = nt.SynthShort(sites_seed=5, n_sites=2000, read_seed=1, p_embed=0.9, sites_path=sp)
