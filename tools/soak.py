@@ -30,7 +30,7 @@ tmp = tempfile.mkdtemp(prefix="ntsm_soak_")
 t_end, it, fails = time.time() + budget, 0, 0
 while time.time() < t_end:
     it += 1
-    k = rng.choice([19, 19, 19, 19, 15, 21, 25, 31, 32, 11])
+    k = rng.choice([19, 19, 19, 13, 14, 15, 16, 17, 18, 20, 21, 24, 25, 31, 32, 11])
     n_sites = rng.choice([5, 50, 400, 3000])
     # sites: ref/var windows around a SNP, k-mers joined by N like the reference's site files
     genome = dna(n_sites * 80)
