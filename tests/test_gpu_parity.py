@@ -607,6 +607,25 @@ def test_bench_two_ranks_over_rccl(nt):
     assert "RCCL SUM" in line["config"]["parallelism"]
 
 
+def test_bench_rccl_path_on_one_rank(nt):
+    """The N > 1 code of bench.py on the one GPU there is: NTSM_FORCE_DIST=1 under torch.distributed.run with a single rank
+    goes through init_process_group("nccl"), the device-side gather, the RCCL all-reduce of the count vector, the import,
+    the barriers and the MAX over ranks.  Merging a vector with itself over one rank must leave the totals of a plain run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NTSM_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "2e6", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1])
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "2e6", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert q.returncode == 0, q.stderr.decode()[-2000:]
+    e = json.loads([l for l in q.stdout.decode().split("\n") if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["check"]["total_kmers_per_step"] == e["check"]["total_kmers_per_step"] and d["check"]["total_hits_per_step"] == e["check"]["total_hits_per_step"]
+    assert e["check"]["equals_sum_of_pieces_below_2GiB"] is True
+
+
 def test_early_stop_across_chunks(nt, n10):
     """The armed path walks big batches in chunks of 2^20 reads: a threshold that trips in the second chunk of a
     resident 1.3 M-read batch stops at the oracle's read, with the oracle's totals and counts."""
