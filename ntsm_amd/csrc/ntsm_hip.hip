@@ -1354,10 +1354,10 @@ int read_device_totals(ntsm_ctx *c, uint64_t out[2])
 int armed_batch(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t n_bytes,
 		const uint64_t *d_read_end, const uint64_t *h_read_end_or_null, uint64_t n_reads)
 {
-	(void) n_bytes;
-	/* The batch is walked in chunks of kArmedChunkReads reads so that the work done is proportional to
-	 * what is consumed before the stop, not to the size of the batch. */
-	constexpr uint64_t CH = 1ull << 20;
+	/* The batch is walked in chunks of reads -- about 256 MB of stream each, at most 2^20 reads -- so that the work done is
+	 * proportional to what is consumed before the stop, not to the size of the batch. */
+	const uint64_t avg_len = std::max<uint64_t>(1, n_bytes / std::max<uint64_t>(1, n_reads));
+	const uint64_t CH = std::min<uint64_t>(1ull << 20, std::max<uint64_t>(1024, (256ull << 20) / avg_len));
 	const uint64_t n_chunks = (n_reads + CH - 1) / CH;
 	std::vector<uint64_t> bend(n_chunks);                 /* offset of the last terminator of every chunk */
 	if (h_read_end_or_null) {
@@ -1378,23 +1378,45 @@ int armed_batch(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t n_
 	uint64_t run[2];
 	int rc = read_device_totals(c, run);
 	if (rc) return rc;
-	for (uint64_t k = 0; k < n_chunks; ++k) {
-		const uint64_t r0 = k * CH, r1 = std::min(n_reads, r0 + CH), nr = r1 - r0;
-		const uint64_t lo = k ? bend[k - 1] + 1 : 0, hi = bend[k] + 1;
-		HIPCHK(hipMemsetAsync(c->d_read_hits, 0, nr * sizeof(uint32_t), st));
-		rc = launch_count(c, st, d_bases, lo, hi, d_read_end + r0, nr, true, +1);
+	/* Optimistic spans.  The per-read kernel (hits attributed to reads, 3 waves per SIMD) is only needed in the one chunk
+	 * where the threshold is crossed.  Everything before it is counted by the plain kernel in spans of whole chunks, sized
+	 * from the hit rate seen so far to use about half of the remaining budget; a span that crosses after all is taken out
+	 * again (sign -1, exact) and walked chunk by chunk, and the crossing chunk is taken out and counted per read. */
+	double rate = -1.0;                                    /* hits per read in the spans accepted so far */
+	bool single = false;                                   /* a span crossed: one chunk at a time from here on */
+	for (uint64_t k = 0; k < n_chunks;) {
+		uint64_t span = 1;
+		if (!single && rate >= 0) {
+			const double budget = (double) (c->max_hits - run[1]);
+			const double reads_ok = rate > 0 ? budget / (2.0 * rate) : 1e18;
+			span = reads_ok >= (double) (64 * CH) ? 64 : std::max<uint64_t>(1, (uint64_t) (reads_ok / (double) CH));
+			span = std::min(span, n_chunks - k);
+		}
+		const uint64_t r0 = k * CH, r1 = std::min(n_reads, (k + span) * CH), nr = r1 - r0;
+		const uint64_t lo = k ? bend[k - 1] + 1 : 0, hi = bend[k + span - 1] + 1;
+		rc = launch_count(c, st, d_bases, lo, hi, nullptr, 0, false, +1);
 		if (rc) return rc;
 		HIPCHK(hipStreamSynchronize(st));
 		uint64_t after[2];
 		rc = read_device_totals(c, after);
 		if (rc) return rc;
-		if (after[1] <= c->max_hits) {                    /* no crossing in this chunk */
+		if (after[1] <= c->max_hits) {                    /* no crossing in this span */
 			c->total_bases += (hi - lo) - nr;
 			c->reads_consumed += nr;
+			rate = (double) (after[1] - run[1]) / (double) nr;
 			run[1] = after[1];
+			k += span;
 			continue;
 		}
-		/* crossing: first read r* (strict '>') after which the cumulative hit count exceeds max_hits */
+		rc = launch_count(c, st, d_bases, lo, hi, nullptr, 0, false, -1);   /* take the span out again */
+		if (rc) return rc;
+		if (span > 1) { single = true; continue; }
+		/* the crossing chunk, per read */
+		HIPCHK(hipMemsetAsync(c->d_read_hits, 0, nr * sizeof(uint32_t), st));
+		rc = launch_count(c, st, d_bases, lo, hi, d_read_end + r0, nr, true, +1);
+		if (rc) return rc;
+		HIPCHK(hipStreamSynchronize(st));
+		/* first read r* (strict '>') after which the cumulative hit count exceeds max_hits */
 		std::vector<uint32_t> hits(nr);
 		HIPCHK(hipMemcpy(hits.data(), c->d_read_hits, nr * sizeof(uint32_t), hipMemcpyDeviceToHost));
 		std::vector<uint64_t> re_local;
