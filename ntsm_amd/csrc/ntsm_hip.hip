@@ -1357,7 +1357,8 @@ int armed_batch(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t n_
 	/* The batch is walked in chunks of reads -- about 256 MB of stream each, at most 2^20 reads -- so that the work done is
 	 * proportional to what is consumed before the stop, not to the size of the batch. */
 	const uint64_t avg_len = std::max<uint64_t>(1, n_bytes / std::max<uint64_t>(1, n_reads));
-	const uint64_t CH = std::min<uint64_t>(1ull << 20, std::max<uint64_t>(1024, (256ull << 20) / avg_len));
+	static const uint64_t chunk_bytes = [] { const char *e = getenv("NTSM_ARMED_CHUNK_BYTES"); return e && atoll(e) > 0 ? (uint64_t) atoll(e) : (256ull << 20); }();   /* tests shrink it */
+	const uint64_t CH = std::min<uint64_t>(1ull << 20, std::max<uint64_t>(1024, chunk_bytes / avg_len));
 	const uint64_t n_chunks = (n_reads + CH - 1) / CH;
 	std::vector<uint64_t> bend(n_chunks);                 /* offset of the last terminator of every chunk */
 	if (h_read_end_or_null) {

@@ -657,6 +657,42 @@ def test_early_stop_across_chunks(nt, n10):
     ctx.close()
 
 
+def test_early_stop_when_a_long_optimistic_span_crosses(n10, tmp_path):
+    """The armed path counts optimistically in spans of chunks sized from the hit rate so far.  A stream whose first 60 %
+    has no site k-mers makes that rate zero, so the second span covers everything that is left, crosses inside the dense
+    part, is taken out again and walked chunk by chunk down to the crossing read.  Small chunks (NTSM_ARMED_CHUNK_BYTES)
+    make this a 30-chunk batch; the run is a subprocess because the library reads the knob once."""
+    s, sites, path = n10
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import ntsm_amd as nt
+from oracle_binding import OracleFP
+path = %r
+sites = nt.Sites(path)
+quiet = nt.SynthShort(20241218, 96287, read_seed=31, p_embed=0.0)
+dense = nt.SynthShort(20241218, 96287, read_seed=32, p_embed=1.0)
+n0, n1 = 120000, 80000
+bases = np.concatenate([quiet.host_bytes(0, n0), dense.host_bytes(0, n1)])
+ends = (np.arange(n0 + n1, dtype=np.uint64) * np.uint64(quiet.stride)) + np.uint64(quiet.read_len)
+full = OracleFP(path); full.process_flat(bases, ends)
+thr = int(full.total_hits * 0.3)
+fp = OracleFP(path, cov=2.0 * (thr + 0.5) / len(sites.keys)); assert fp.max_hits == thr
+fp.process_flat(bases, ends); assert fp.early_term and fp.reads_processed > n0 + 1000
+ctx = nt.Context(sites.keys, max_hits=thr)
+ctx.submit(bases, ends)
+t = ctx.sync()
+st = ctx.debug_stats()
+assert t.early_stop == 1 and t.reads_consumed == fp.reads_processed, (t.reads_consumed, fp.reads_processed)
+assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases)
+assert np.array_equal(ctx.counts(), fp.kmers()[2])
+assert st["launches_k19"] >= 8, st                      # spans, their undo, single chunks, the per-read chunk, the tail
+print("ok", t.reads_consumed, st["launches_k19"])
+""" % (ROOT, os.path.join(ROOT, "tests"), path)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, NTSM_ARMED_CHUNK_BYTES=str(1 << 20)))
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
+
+
 def test_ordered_early_stop_over_several_contexts(nt, n10):
     """ntsm_amd.dist.OrderedEarlyStop with ContextEngine: three contexts (stand-ins for three GPUs/ranks, driven by
     three threads with a barrier all-gather) consume super-batches split in rank order; the global -m stop equals one

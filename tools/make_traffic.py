@@ -14,9 +14,16 @@ KERNEL_SOURCES = ["ntsm_amd/csrc/ntsm_hip.hip", "ntsm_amd/csrc/ntsm_device.h", "
 
 
 def kernel_source_sha16():
+    """SHA-256 over the device code: ntsm_device.h, the tabulated kernel's include and the part of ntsm_hip.hip in front of
+    its ' * Host code' banner (edits to the host half of that file do not change any kernel)."""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+        data = open(os.path.join(ROOT, f), "rb").read()
+        if f.endswith("ntsm_hip.hip"):
+            cut = data.find(b"\n * Host code")
+            assert cut > 0, "ntsm_hip.hip: ' * Host code' banner not found"
+            data = data[:cut]
+        h.update(data)
     return h.hexdigest()[:16]
 
 
