@@ -679,15 +679,18 @@ full = OracleFP(path); full.process_flat(bases, ends)
 thr = int(full.total_hits * 0.3)
 fp = OracleFP(path, cov=2.0 * (thr + 0.5) / len(sites.keys)); assert fp.max_hits == thr
 fp.process_flat(bases, ends); assert fp.early_term and fp.reads_processed > n0 + 1000
-ctx = nt.Context(sites.keys, max_hits=thr)
-ctx.submit(bases, ends)
-t = ctx.sync()
-st = ctx.debug_stats()
-assert t.early_stop == 1 and t.reads_consumed == fp.reads_processed, (t.reads_consumed, fp.reads_processed)
-assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases)
-assert np.array_equal(ctx.counts(), fp.kmers()[2])
-assert st["launches_k19"] >= 8, st                      # spans, their undo, single chunks, the per-read chunk, the tail
-print("ok", t.reads_consumed, st["launches_k19"])
+for variant in (0, 3, 1):                                # minimizer-blocked, tabulated (its spans and undo passes), generic
+    ctx = nt.Context(sites.keys, max_hits=thr)
+    ctx.set_kernel(variant)
+    ctx.submit(bases, ends)
+    t = ctx.sync()
+    st = ctx.debug_stats()
+    assert t.early_stop == 1 and t.reads_consumed == fp.reads_processed, (variant, t.reads_consumed, fp.reads_processed)
+    assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases), variant
+    assert np.array_equal(ctx.counts(), fp.kmers()[2]), variant
+    assert st["launches_k19"] + st["launches_tab"] + st["launches_generic"] >= 8, st   # spans, their undo, single chunks, the per-read chunk, the tail
+    ctx.close()
+print("ok", t.reads_consumed)
 """ % (ROOT, os.path.join(ROOT, "tests"), path)
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, NTSM_ARMED_CHUNK_BYTES=str(1 << 20)))
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
