@@ -29,8 +29,14 @@ build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp 
 	$(CXX) $(CXXFLAGS) -o $@ $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp \
 	    -Lntsm_amd -lntsm_hip -lz -pthread -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
-ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h
+ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_device.h include/ntsm_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ntsm_hip.hip -ldl
+
+# the same ABI with the tabulated k = 19 kernel compiled in (ntsm_set_kernel(ctx, 3)): a measured negative result kept
+# buildable and tested (tests/test_gpu_parity.py::test_tabulated_kernel_paths loads it through NTSM_HIP_LIB), not shipped
+tab: ntsm_amd/libntsm_hip_tab.so
+ntsm_amd/libntsm_hip_tab.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h
+	$(HIPCC) $(HIPFLAGS) -DNTSM_WITH_TAB -shared -o $@ $(CSRC)/ntsm_hip.hip -ldl
 
 # ntsmEval all-pairs scoring: own library, own CLI
 ntsm_amd/libntsm_eval_hip.so: $(CSRC)/ntsm_eval.hip include/ntsm_eval_hip.h
@@ -43,7 +49,7 @@ build/ntsmEval: $(HOST)/ntsm_eval_main.cpp include/ntsm_eval_hip.h ntsm_amd/libn
 
 # ablation builds of the tabulated kernel for tools/ab_libs.sh (never shipped: wrong counts by construction)
 ablation: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h
-	for a in $(or $(ABL),1 2 4 5 7 8); do $(HIPCC) $(HIPFLAGS) -DNTSM_ABLATION -DNTSM_TAB_ABL=$$a -shared -o ntsm_amd/libntsm_hip_abl$$a.so $(CSRC)/ntsm_hip.hip -ldl & done; wait
+	for a in $(or $(ABL),1 2 4 5 7 8); do $(HIPCC) $(HIPFLAGS) -DNTSM_WITH_TAB -DNTSM_ABLATION -DNTSM_TAB_ABL=$$a -shared -o ntsm_amd/libntsm_hip_abl$$a.so $(CSRC)/ntsm_hip.hip -ldl & done; wait
 
 ntsm_amd/libntsm_synth.so: $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp -lz
@@ -62,4 +68,4 @@ build/gather_bench: tools/gather_bench.hip
 clean:
 	rm -rf build ntsm_amd/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle_all clean ablation
+.PHONY: all oracle_all clean ablation tab

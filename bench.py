@@ -3,16 +3,26 @@
 
 One "step" = one pass of the count path over the whole resident workload (BASELINE.json configs[1]:
 1e9 synthetic 150 bp reads against the 96287-site hs_n10_like set, k = 19), inputs already in HBM.
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own 1e9 reads
-(weak scaling, configs[3]); each step ends with one RCCL SUM of the per-k-mer count vector + totals.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the count kernel: algorithmic bytes =
-(L + 8) / L per base over the HIP-event launch time; `cpu_baseline` is the CPU
-restatement of the reference (oracle/ntsm_oracle) timed on a bounded sample of the same reads.
+N > 1 (configs[3]): one rank per GPU, every rank owns its own 1e9 reads (weak scaling); each step ends with one
+RCCL SUM of the per-k-mer count vector + totals.  The ranks are started either by torch.distributed.run
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or by this script itself: `python bench.py --gpus N` with no WORLD_SIZE spawns N fresh child processes
+BEFORE anything in the parent touches the GPU, one per device, and passes rank 0's JSON line through.  A request for
+more GPUs than the box has, or a WORLD_SIZE that differs from --gpus, ends with a non-zero exit status and no JSON
+line -- never an N = 1 line for an N > 1 request.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the count kernel: algorithmic bytes = (L + 8) / L per base
+ over the HIP-event launch time; `cpu_baseline` is the reference's CPU path timed on a bounded sample of
+the same reads.  At N = 1 the line also carries `other_configs`: BASELINE.json configs[2] (long reads, with and
+without -m 10), configs[4] (1 M sites) and the file -> counts.txt path through build/ntsmCount, each with its own
+correctness check.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -21,9 +31,73 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r02_traffic.json"   # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
+TRAFFIC_FILE = "r03_traffic.json"          # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
+STRESS_TRAFFIC_FILE = "r03_stress_traffic.json"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 SITES_SEED, N_SITES, READ_SEED, READ_LEN, K = 20241218, 96287, 7, 150, 19
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=float, default=float(os.environ.get("NTSM_BENCH_READS", 1e9)),
+                    help="reads per GPU (default 1e9 = BASELINE.json configs[1])")
+    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--filter-log2", type=int, default=0)
+    ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (minimizer-blocked kernel for k=19), 1 generic")
+    ap.add_argument("--no-check", action="store_true", help="skip the correctness check of the timed result")
+    ap.add_argument("--other-configs", default="long,stress,e2e",
+                    help="comma list of the secondary single-GPU measurements appended at N = 1 ('' or 'none': skip)")
+    ap.add_argument("--long-reads", type=float, default=5e6)
+    ap.add_argument("--stress-sites", type=float, default=1e6)
+    ap.add_argument("--stress-reads", type=float, default=2e8)
+    ap.add_argument("--e2e-reads", type=float, default=4e7, help="reads of the FASTQ the CLI leg counts (4e7 = 12.6 GB)")
+    ap.add_argument("--e2e-threads", type=int, default=16)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch test: every rank prints its rank environment as one JSON line and exits before touching the GPU")
+    return ap.parse_args(argv)
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks ourselves.  Nothing here may initialise the GPU (a process that has must
+# not be replaced or forked into ranks): the parent only counts devices and starts children.
+# -----------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    n = args.gpus
+    if not args.dry_launch:
+        import torch                                     # device_count() does not create a GPU context
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to run a smaller job "
+                             "under that name\n" % (n, have))
+            return 3
+    with socket.socket() as s:                           # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   NTSM_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in live:                           # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+    return rc
 
 
 def cpu_baseline(synth, sites_path, n_reads, n_files=1):
@@ -33,62 +107,241 @@ def cpu_baseline(synth, sites_path, n_reads, n_files=1):
     n_files files (src/FingerPrint.hpp:47)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_ntsmCount")
     port = os.path.join(ROOT, "oracle", "ntsm_oracle")
+    out = {}
     with tempfile.TemporaryDirectory() as d:
         files = []
         for i in range(n_files):
             fq = os.path.join(d, "sample%d.fq" % i)
-            synth.write_fastq(fq, i * n_reads, n_reads)
+            synth.write_fastq(fq, i * n_reads, n_reads, threads=4)
             files.append(fq)
+        runs = []
         if os.path.exists(ref):
-            kind = "reference"
-            p = subprocess.run([ref, "-s", sites_path, "-t", str(n_files)] + files, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                               env=dict(os.environ, NTSM_REF_TIME_SCAN="1"))
-        elif os.path.exists(port) and n_files == 1:
-            kind = "port"
-            p = subprocess.run([port, "-s", sites_path, "--time-scan", files[0]], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        else:
-            return None
-    secs = bases = None
-    for line in p.stderr.decode().split("\n"):
-        f = line.split()
-        if line.startswith("SCAN_SECONDS"):
-            secs = float(f[1])
-            if len(f) > 3:
-                bases = int(f[3])
-        elif line.startswith("Total Bases Considered:"):
-            bases = int(f[-1])
-    if not secs or not bases:
-        return None
-    return {"value": bases / secs, "unit": "bases/s", "cores": n_files, "kind": kind,
-            "sample": "%d x %d reads of the same synthetic stream as FASTQ (%d bases, %.1f s scan, table build excluded)"
-                      % (n_files, n_reads, bases, secs)}
+            runs.append(("reference", [ref, "-s", sites_path, "-t", str(n_files)] + files, dict(os.environ, NTSM_REF_TIME_SCAN="1")))
+        if os.path.exists(port) and n_files == 1:
+            runs.append(("port", [port, "-s", sites_path, "--time-scan", files[0]], dict(os.environ)))
+        for kind, cmd, env in runs:
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+            secs = bases = None
+            for line in p.stderr.decode().split("\n"):
+                f = line.split()
+                if line.startswith("SCAN_SECONDS"):
+                    secs = float(f[1])
+                    if len(f) > 3:
+                        bases = int(f[3])
+                elif line.startswith("Total Bases Considered:"):
+                    bases = int(f[-1])
+            if secs and bases:
+                out[kind] = {"value": bases / secs, "unit": "bases/s", "cores": n_files, "kind": kind,
+                             "sample": "%d x %d reads of the same synthetic stream as FASTQ (%d bases, %.1f s scan, table build excluded)"
+                                       % (n_files, n_reads, bases, secs)}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=float, default=float(os.environ.get("NTSM_BENCH_READS", 1e9)),
-                    help="reads per GPU (default 1e9 = BASELINE.json configs[1])")
-    ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--filter-log2", type=int, default=0)
-    ap.add_argument("--grid", type=int, default=0)
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto (minimizer-blocked kernel for k=19), 1 generic, 3 tabulated")
-    ap.add_argument("--no-check", action="store_true", help="skip the sum-of-pieces correctness check of the timed result")
-    args = ap.parse_args()
+def pmc_constants(name, kernel_variant_ok=True):
+    """PMC-derived per-base constants (separate rocprofv3 --pmc passes, tools/profile.sh + tools/make_traffic.py).  They
+    are tied to the build they were measured on: after any change to the kernel sources, the launch code or the build
+    flags they are reported as null until the profile has been taken again."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from make_traffic import kernel_source_sha16
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if tj.get("kernel_source_sha16") == kernel_source_sha16() and kernel_variant_ok:
+            return tj, "profiles/%s" % name
+        return None, "null: profiles/%s was measured on other kernel sources (or another kernel variant)" % name
+    except Exception:
+        return None, "null: no PMC profile of the current kernel sources under profiles/"
+
+
+def timed_passes(ctx, ptr, n_bytes, n_reads, reps):
+    """warm pass, reset, `reps` passes bracketed by the library's HIP events: (totals, ms per launch)"""
+    ctx.count_resident(ptr, n_bytes, 0, n_reads)
+    ctx.sync()
+    ctx.reset()
+    ctx.set_timing(True)
+    for _ in range(reps):
+        ctx.count_resident(ptr, n_bytes, 0, n_reads)
+    t = ctx.sync()
+    n, ms = ctx.get_timing()
+    ctx.set_timing(False)
+    return t, ms / max(n, 1)
+
+
+def generic_reference(nt, keys, ptr, n_bytes, n_reads, device):
+    """The same resident stream through the GENERIC kernel (ntsm_count_kernel: byte-wise rolling, 1-bit filter, no
+    minimizers -- it shares only the key table and the counters with the kernel being timed): (k-mers, hits, counts)."""
+    ref = nt.Context(keys, k=K, device=device)
+    ref.set_kernel(1)
+    ref.count_resident(ptr, n_bytes, 0, n_reads)
+    t = ref.sync()
+    out = (t.total_kmers, t.total_hits, ref.counts())
+    ref.close()
+    return out
+
+
+def config_long(nt, torch, dev, local, synth, sites, args):
+    """BASELINE.json configs[2]: ONT-like long reads (log-normal lengths, N50 ~ 20 kb, 5 % substitutions) resident in HBM,
+    plain pass and -m 10 exact early stop."""
+    import numpy as np
+    n_reads = int(args.long_reads)
+    L = nt.SynthLong(synth, read_seed=13, spacing=16000)
+    ends, total = L.layout(0, n_reads)
+    bases = int(total) - n_reads
+    d_win = torch.from_numpy(synth.windows).to(dev)
+    d_ends = torch.from_numpy(ends.view(np.int64)).to(dev)
+    d_bases = torch.empty(total, dtype=torch.uint8, device=dev)
+    L.device_fill(d_win.data_ptr(), 0, n_reads, d_ends.data_ptr(), total, d_bases.data_ptr())
+    torch.cuda.synchronize()
+    ctx = nt.Context(sites.keys, k=K, device=local)
+    reps = 2
+    t, ms = timed_passes(ctx, d_bases.data_ptr(), total, n_reads, reps)
+    counts = ctx.counts()
+    ctx.close()
+    check = {}
+    if not args.no_check:
+        rk, rh, rc = generic_reference(nt, sites.keys, d_bases.data_ptr(), total, n_reads, local)
+        assert (t.total_kmers, t.total_hits) == (reps * rk, reps * rh) and (counts == rc * reps).all(), \
+            "long reads: minimizer-blocked kernel and generic kernel disagree"
+        check["equals_generic_kernel_on_the_whole_stream"] = True
+    alg_bytes = bases + 8 * n_reads
+    out = {"workload": "configs[2]: %.3g synthetic ONT-like reads (%.1f Gbases, mean %.0f b), hs_n10_like sites" % (n_reads, bases / 1e9, bases / n_reads),
+           "reads": n_reads, "bases": bases, "kernel_ms": ms, "gbases_per_s": bases / ms / 1e6,
+           "roofline_frac": alg_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_base": alg_bytes / bases,
+           "hits_per_pass": t.total_hits // reps}
+    # -m 10: the exact early stop (src/FingerPrint.hpp:473-488) on the same resident stream
+    thr = nt.max_hits_for(len(sites.keys), 10.0)
+    ctx = nt.Context(sites.keys, k=K, device=local, max_hits=thr)
+    t0 = time.perf_counter()
+    ctx.count_resident(d_bases.data_ptr(), total, d_ends.data_ptr(), n_reads)
+    tm = ctx.sync()
+    wall = time.perf_counter() - t0
+    ctx.close()
+    m10 = {"max_hits": thr, "early_stop": bool(tm.early_stop), "stop_read": tm.reads_consumed, "frac_of_stream": tm.reads_consumed / n_reads,
+           "total_hits": tm.total_hits, "wall_s": wall, "bases_consumed": tm.total_bases}
+    if not args.no_check and tm.early_stop and tm.reads_consumed >= 1:
+        # the stop read is exact iff the prefix WITHOUT it stays at or below the threshold and the prefix WITH it exceeds it;
+        # both prefixes are recounted unarmed by the generic kernel (offset 0: aligned)
+        r = tm.reads_consumed
+        with_it = generic_reference(nt, sites.keys, d_bases.data_ptr(), int(ends[r - 1]) + 1, r, local)
+        without = generic_reference(nt, sites.keys, d_bases.data_ptr(), int(ends[r - 2]) + 1, r - 1, local) if r >= 2 else (0, 0, None)
+        assert with_it[1] == tm.total_hits and with_it[1] > thr >= without[1], "-m 10: stop read is not the first crossing read"
+        m10["stop_read_is_first_crossing_by_generic_kernel_recount"] = True
+    out["m10"] = m10
+    out["check"] = check
+    del d_bases
+    torch.cuda.empty_cache()
+    return out
+
+
+def config_stress(nt, torch, dev, local, args, tmp):
+    """BASELINE.json configs[4]: 1 M sites (16 M site k-mers, 512 MiB key table), 150 bp reads resident in HBM."""
+    n_sites, n_reads = int(args.stress_sites), int(args.stress_reads)
+    sp = os.path.join(tmp, "stress.fa")
+    t0 = time.perf_counter()
+    s = nt.SynthShort(424242, n_sites, read_seed=9, sites_path=sp)
+    sites = nt.Sites(sp, k=K)
+    t_sites = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ctx = nt.Context(sites.keys, k=K, device=local)
+    t_create = time.perf_counter() - t0
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d_bases = torch.empty(n_reads * s.stride, dtype=torch.uint8, device=dev)
+    s.device_fill(d_win.data_ptr(), 0, n_reads, d_bases.data_ptr())
+    torch.cuda.synchronize()
+    reps = 2
+    t, ms = timed_passes(ctx, d_bases.data_ptr(), d_bases.numel(), n_reads, reps)
+    counts = ctx.counts()
+    ctx.close()
+    check = {}
+    if not args.no_check:
+        rk, rh, rc = generic_reference(nt, sites.keys, d_bases.data_ptr(), d_bases.numel(), n_reads, local)
+        assert (t.total_kmers, t.total_hits) == (reps * rk, reps * rh) and (counts == rc * reps).all(), \
+            "1 M sites: minimizer-blocked kernel and generic kernel disagree"
+        check["equals_generic_kernel_on_the_whole_stream"] = True
+    bases = n_reads * READ_LEN
+    tj, note = pmc_constants(STRESS_TRAFFIC_FILE)
+    out = {"workload": "configs[4]: %.3g sites (%d site 19-mers), %.3g synthetic 150 bp reads" % (n_sites, len(sites.keys), n_reads),
+           "reads": n_reads, "site_kmers": len(sites.keys), "kernel_ms": ms, "gbases_per_s": bases / ms / 1e6,
+           "roofline_frac": bases * (READ_LEN + 8) / READ_LEN / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+           "hits_per_pass": t.total_hits // reps, "site_gen_and_load_s": t_sites, "create_s": t_create,
+           "fabric_read_requests_per_base_from_pmc": tj.get("fabric_read_requests_per_base") if tj else None,
+           "l2_requests_per_base_from_pmc": tj.get("l2_requests_per_base") if tj else None, "pmc_source": note,
+           "check": check}
+    del d_bases
+    torch.cuda.empty_cache()
+    return out
+
+
+def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
+    """File -> counts.txt through the CLI (build/ntsmCount -t N) on a generated plain FASTQ, the whole process timed;
+    its stdout must equal what the resident path prints for the same reads."""
+    n_reads = int(args.e2e_reads)
+    fq = os.path.join(tmp, "e2e.fq")
+    t0 = time.perf_counter()
+    synth.write_fastq(fq, 0, n_reads, threads=max(1, min(32, (os.cpu_count() or 2) - 1)))
+    t_gen = time.perf_counter() - t0
+    size = os.path.getsize(fq)
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    best = None
+    for _ in range(2):                                     # second run: file certainly in the page cache
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "-s", sites_path, "-t", str(args.e2e_threads), "-g", str(local), fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, NTSM_PHASE_TIMES="1"))
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            raise RuntimeError("ntsmCount failed: " + p.stderr.decode()[-400:])
+        if best is None or wall < best[0]:
+            best = (wall, p)
+    wall, p = best
+    os.unlink(fq)
+    phases = [l[8:] for l in p.stderr.decode().split("\n") if l.startswith("[phase]")]
+    parse_s = None
+    for l in phases:
+        if "parse+count" in l:
+            try:
+                parse_s = float(l.split("parse+count")[1].split("s")[0])
+            except ValueError:
+                pass
+    # the same reads resident in HBM through the C ABI, printed by the same report code
+    d_win = torch.from_numpy(synth.windows).to(dev)
+    d_bases = torch.empty(n_reads * synth.stride, dtype=torch.uint8, device=dev)
+    synth.device_fill(d_win.data_ptr(), 0, n_reads, d_bases.data_ptr())
+    torch.cuda.synchronize()
+    ctx = nt.Context(sites.keys, k=K, device=local)
+    ctx.count_resident(d_bases.data_ptr(), d_bases.numel(), 0, n_reads)
+    t = ctx.sync()
+    rc, text = sites.format_counts(ctx.counts(), t.total_kmers)
+    ctx.close()
+    del d_bases
+    torch.cuda.empty_cache()
+    sha_cli, sha_res = hashlib.sha256(p.stdout).hexdigest(), hashlib.sha256(text).hexdigest()
+    assert rc == 0 and sha_cli == sha_res, "CLI counts.txt differs from the resident path's"
+    bases = n_reads * READ_LEN
+    return {"workload": "build/ntsmCount -t %d on one plain FASTQ of %.3g reads (%.1f GB, page cache), hs_n10_like sites" % (args.e2e_threads, n_reads, size / 1e9),
+            "reads": n_reads, "file_bytes": size, "wall_s": wall, "gbases_per_s": bases / wall / 1e9,
+            "parse_and_count_s": parse_s, "gbases_per_s_parse_and_count": bases / parse_s / 1e9 if parse_s else None,
+            "phases": phases, "fastq_gen_s": t_gen, "counts_sha256": sha_cli, "check": {"counts_txt_equals_resident_path": True}}
+
+
+def run_rank(args):
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local, "world_size": world, "gpus": args.gpus,
+                          "master_addr": os.environ.get("MASTER_ADDR"), "master_port": os.environ.get("MASTER_PORT"),
+                          "pid": os.getpid(), "ppid": os.getppid()}), flush=True)
+        return 0
 
     import torch
     import torch.distributed as dist
     import ntsm_amd
-    from ntsm_amd.dist import merge_counts, shard_range
+    from ntsm_amd.dist import merge_counts
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the count path has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d wants device %d but this node exposes %d GPU(s)\n" % (rank, local, torch.cuda.device_count()))
+        return 3
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or bool(os.environ.get("NTSM_FORCE_DIST"))     # force: exercise the RCCL path on one rank
@@ -127,12 +380,16 @@ def main():
         if use_dist:
             merge_counts(ctx)
 
-    # Correctness of the timed launch at full size (byte offsets far beyond 2^32): the same resident stream counted in
+    # Correctness of the timed launch at full size (byte offsets far beyond 2^32), independent of the kernel being timed:
+    # the same resident stream counted by the GENERIC kernel (no minimizers, no blocked filter, its own rolling code) in
     # read-aligned pieces of < 2 GiB on a second context, each piece re-based so that its offsets are small.  The timed
-    # context must reproduce these totals and per-k-mer counts exactly (checked after the timed region).
+    # context must reproduce these totals and per-k-mer counts exactly (checked after the timed region).  Oracle parity of
+    # both kernels is the job of tests/test_gpu_parity.py.
     expect = None
     if not args.no_check and not use_dist:
         ref = ntsm_amd.Context(sites.keys, k=K, device=local)
+        if args.kernel != 1:
+            ref.set_kernel(1)
         piece = 13_000_000 // 16 * 16                     # 1.96 GB; a multiple of 16 reads keeps the piece bases 16-byte aligned
         for r0 in range(0, n_reads, piece):
             m = min(piece, n_reads - r0)
@@ -157,43 +414,36 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = ctx.get_timing()
+    ctx.set_timing(False)
     totals = ctx.sync()
     checked = False
     if expect is not None:
         reps = args.steps + args.warmup
         assert (totals.total_kmers, totals.total_hits) == (reps * expect[0], reps * expect[1]), \
-            "timed launches disagree with the sum over < 2 GiB pieces: %r vs %d x %r" % ((totals.total_kmers, totals.total_hits), reps, expect[:2])
-        assert (ctx.counts() == expect[2] * reps).all(), "per-k-mer counts of the timed launches differ from the sum over pieces"
+            "timed launches disagree with the generic kernel's sum over < 2 GiB pieces: %r vs %d x %r" % ((totals.total_kmers, totals.total_hits), reps, expect[:2])
+        assert (ctx.counts() == expect[2] * reps).all(), "per-k-mer counts of the timed launches differ from the generic kernel's sum over pieces"
         checked = True
 
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    ctx.close()
+    del d_bases
+    torch.cuda.empty_cache()
 
     if rank == 0:
         value = world * bases_per_step * args.steps / elapsed
         launch_s = kernel_ms / 1e3 / max(n_launch, 1)
         bytes_per_base = (READ_LEN + 8) / READ_LEN
         achieved = bases_per_step * bytes_per_base / launch_s / 1e9
-        # PMC-derived constants (separate rocprofv3 --pmc passes, tools/profile.sh + tools/make_traffic.py): bytes per launch,
-        # VALU share, L2 request rate.  They are tied to the kernel sources they were measured on: after any change to those
-        # files they are reported as null until the profile has been taken again.
+        tj, traffic_note = pmc_constants(TRAFFIC_FILE, args.kernel in (0, 2))
         traffic = valu_busy = l2_frac = None
-        traffic_note = "null: no PMC profile of the current kernel sources under profiles/"
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            from make_traffic import kernel_source_sha16
-            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
-            if tj.get("kernel_source_sha16") == kernel_source_sha16() and args.kernel in (0, 2):
-                traffic = tj["traffic_bytes_per_base"] * bases_per_step
-                valu_busy, l2_frac = tj.get("valu_busy_frac"), tj.get("l2_request_rate_frac_of_cap")
-                traffic_note = ("fabric-side bytes/launch from FETCH_SIZE+WRITE_SIZE (profiles/%s): L2 misses of filter/table "
-                                "served by the Infinity Cache + the stream; not HBM re-reads" % TRAFFIC_FILE)
-            else:
-                traffic_note = "null: profiles/%s was measured on other kernel sources (or another kernel variant)" % TRAFFIC_FILE
-        except Exception:
-            pass
+        if tj:
+            traffic = tj["traffic_bytes_per_base"] * bases_per_step
+            valu_busy, l2_frac = tj.get("valu_busy_frac"), tj.get("l2_request_rate_frac_of_cap")
+            traffic_note = ("fabric-side bytes/launch from FETCH_SIZE+WRITE_SIZE (%s): L2 misses of filter/table "
+                            "served by the Infinity Cache + the stream; not HBM re-reads" % traffic_note)
         out = {
             "metric": "bases/s (and reads/s) through ntsmCount, 150 bp reads vs human_sites_n10.fa",   # BASELINE.json's metric
             "value": value, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,12 +456,14 @@ def main():
                                    "(96287 sites, %d distinct 19-mers), k=19" % (n_reads, len(sites.keys)),
                        "reads_per_gpu": n_reads, "read_len": READ_LEN, "k": K, "n_sites": N_SITES,
                        "parallelism": ("reads sharded over %d GPUs; one RCCL SUM of per-k-mer counts per step" % world) if world > 1
-                                      else "one GPU, no collective"},
+                                      else "one GPU, no collective",
+                       "launched_by": "bench.py --gpus N (self-spawned ranks)" if os.environ.get("NTSM_BENCH_SELF_LAUNCHED") else
+                                      ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "achieved_stream_only_GBs": bases_per_step * (READ_LEN + 1) / READ_LEN / launch_s / 1e9,
-                         "kernel": {0: "ntsm_count_mz_kernel", 2: "ntsm_count_mz_kernel", 3: "ntsm_count_tab19_kernel"}.get(args.kernel, "ntsm_count_kernel"),
+                         "kernel": {0: "ntsm_count_mz_kernel", 2: "ntsm_count_mz_kernel"}.get(args.kernel, "ntsm_count_kernel"),
                          "launches": n_launch, "avg_launch_ms": 1e3 * launch_s,
                          "algorithmic_bytes_per_base": bytes_per_base,
                          "valu_busy_frac_from_pmc": valu_busy,     # share of SIMD issue cycles on VALU
@@ -219,23 +471,67 @@ def main():
                          "kmer_probe_rate_per_s": totals.total_kmers / max(args.steps + args.warmup, 1) / launch_s},
             "check": {"total_kmers_per_step": totals.total_kmers // (args.steps + args.warmup) if world == 1 else None,
                       "total_hits_per_step": totals.total_hits // (args.steps + args.warmup) if world == 1 else None,
-                      "equals_sum_of_pieces_below_2GiB": checked},
+                      "equals_generic_kernel_sum_of_pieces_below_2GiB": checked,
+                      "note": "independent-kernel consistency at full size; oracle parity of both kernels: tests/test_gpu_parity.py"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(synth, sites_path, args.cpu_sample_reads)
-            if cb:
-                out["cpu_baseline"] = cb
-                out["gpu_over_cpu"] = value / cb["value"]
-                if cb["kind"] == "reference":       # the reference's best case: -t N over N files
-                    n_thr = max(2, min(32, (os.cpu_count() or 2) // 2))
-                    mt = cpu_baseline(synth, sites_path, max(1, args.cpu_sample_reads // n_thr), n_thr)   # same total work
+            main_kind = "reference" if "reference" in cb else ("port" if "port" in cb else None)
+            if main_kind:
+                out["cpu_baseline"] = cb[main_kind]
+                out["gpu_over_cpu"] = value / cb[main_kind]["value"]
+                if main_kind == "reference":
+                    # oracle/_ref is the reference compiled in place: it travels to the GPU box as a prebuilt binary only.
+                    # The plain-C port is timed beside it so that the figure survives without that binary.
+                    if "port" in cb:
+                        out["cpu_baseline_port"] = cb["port"]
+                    n_thr = max(2, min(32, (os.cpu_count() or 2) // 2))   # the reference's best case: -t N over N files
+                    mt = cpu_baseline(synth, sites_path, max(1, args.cpu_sample_reads // n_thr), n_thr).get("reference")
                     if mt:
                         out["cpu_baseline_threads"] = mt
-        print(json.dumps(out))
-    ctx.close()
+        which = [w for w in args.other_configs.split(",") if w and w != "none"] if world == 1 and not use_dist else []
+        if which:
+            other = {}
+            for name in which:
+                t0 = time.perf_counter()
+                try:
+                    if name == "long":
+                        other["long"] = config_long(ntsm_amd, torch, dev, local, synth, sites, args)
+                    elif name == "stress":
+                        other["stress"] = config_stress(ntsm_amd, torch, dev, local, args, tmp)
+                    elif name == "e2e":
+                        other["e2e_cli"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp)
+                    else:
+                        continue
+                except AssertionError:
+                    raise                                  # a wrong result is never reported as a number
+                except Exception as e:                     # out of memory / disk on a smaller box: say so, keep the headline
+                    other[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                key = "e2e_cli" if name == "e2e" else name
+                if key in other:
+                    other[key]["leg_wall_s"] = time.perf_counter() - t0
+            out["other_configs"] = other
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if env_world is None:
+        if args.gpus > 1:
+            return launch_ranks(args, argv)                # spawn before anything here touches the GPU
+    elif int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to report one as the other\n"
+                         % (args.gpus, env_world))
+        return 2
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

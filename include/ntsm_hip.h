@@ -141,6 +141,10 @@ int ntsm_counts_device(ntsm_ctx *ctx, void **d_vec, uint64_t *n_words);
 int ntsm_import_reduced(ntsm_ctx *ctx);
 /* Single-process multi-GPU merge: RCCL SUM over the n contexts' count vectors + totals (xGMI). */
 int ntsm_allreduce(ntsm_ctx *const *ctxs, int n);
+/* Bind RCCL now (dlopen of librccl.so.1 + the five entry points ntsm_allreduce calls: ncclCommInitAll, ncclGroupStart,
+ * ncclGroupEnd, ncclAllReduce, ncclCommDestroy) and say whether it worked: NTSM_OK or NTSM_ERR_RCCL.  Touches no GPU.
+ * A multi-device host calls it BEFORE counting, so that a missing RCCL shows up front rather than after the work. */
+int ntsm_rccl_probe(void);
 /* Re-arm or disarm the -m stop of a context.  The threshold is compared (strict '>', after every whole read) with
  * the context's OWN cumulative total_hits, so a caller that orders reads across several contexts passes
  * total_hits_of_this_context + (global threshold - hits counted globally before the next batch); see
@@ -158,10 +162,13 @@ int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
 /* Tuning knobs (0 = automatic): log2 of filter bits (rebuilds the tables: counts and totals restart from zero),
  * grid blocks.  For profiling experiments. */
 int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
+/* An armed (-m) batch is walked in chunks of about chunk_bytes of stream (at most 2^20 reads, at least 1024) so that the work
+ * is proportional to what is consumed before the stop; 0 = the default (256 MiB).  Any value gives the same result. */
+int ntsm_set_armed_chunk(ntsm_ctx *ctx, uint64_t chunk_bytes);
 /* Kernel choice: 0 = automatic (13 <= k <= 31: the minimizer-blocked kernel; other k: the generic kernel), 1 = always the
- * generic kernel, 2 = same as 0, 3 = k == 19 only: the tabulated kernel (table-driven hashes, 2-bit packed tiles, look-up
- * kernel on a second stream; the minimizer-blocked kernel still takes tiles that hold bytes outside ACGTUNacgtun and -m
- * batches).  All give identical results; 3 is measured 7 % slower than 0 on the bench workload. */
+ * generic kernel, 2 = same as 0.  Both kernels give identical results.  3 = the tabulated k = 19 kernel, a measured
+ * negative result (7 % slower) that only exists in -DNTSM_WITH_TAB builds (`make tab`:
+ * ntsm_amd/libntsm_hip_tab.so); the default library answers NTSM_ERR_ARG. */
 int ntsm_set_kernel(ntsm_ctx *ctx, int variant);
 /* Introspection for tests and profiles (implies a sync): out[0] = 64 KiB tiles the tabulated kernel handed to the
  * exact kernel because they hold bytes outside ACGTUNacgtun, out[1..3] = count launches by kernel

@@ -49,6 +49,9 @@ int ntsm_synth_long_fill_device(const ntsm_synth_long *p, const void *d_windows,
 /* Write reads [r0, r0+n_reads) of the short-read stream as FASTQ (quality 'I'); ".gz" => gzip. */
 int ntsm_synth_short_write_fastq(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
 		uint64_t n_reads, const char *path);
+/* The same file (plain output), written by n_threads threads with pwrite() at computed offsets. */
+int ntsm_synth_short_write_fastq_mt(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
+		uint64_t n_reads, const char *path, unsigned n_threads);
 int ntsm_synth_long_write_fastq(const ntsm_synth_long *p, const uint8_t *windows, const uint32_t *qtable257,
 		uint64_t r0, uint64_t n_reads, const char *path);
 

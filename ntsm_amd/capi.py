@@ -71,12 +71,14 @@ _sig(H, "ntsm_counts", C.c_int, [C.c_void_p, u64p])
 _sig(H, "ntsm_counts_device", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), u64p])
 _sig(H, "ntsm_import_reduced", C.c_int, [C.c_void_p])
 _sig(H, "ntsm_allreduce", C.c_int, [C.POINTER(C.c_void_p), C.c_int])
+_sig(H, "ntsm_rccl_probe", C.c_int, [])
 _sig(H, "ntsm_reset", C.c_int, [C.c_void_p])
 _sig(H, "ntsm_set_max_hits", C.c_int, [C.c_void_p, C.c_uint64, C.c_int])
 _sig(H, "ntsm_set_timing", C.c_int, [C.c_void_p, C.c_int])
 _sig(H, "ntsm_get_timing", C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_double)])
 _sig(H, "ntsm_set_tuning", C.c_int, [C.c_void_p, C.c_int, C.c_int])
 _sig(H, "ntsm_set_kernel", C.c_int, [C.c_void_p, C.c_int])
+_sig(H, "ntsm_set_armed_chunk", C.c_int, [C.c_void_p, C.c_uint64])
 _sig(H, "ntsm_stream", C.c_void_p, [C.c_void_p])
 _sig(H, "ntsm_debug_stats", C.c_int, [C.c_void_p, u64p])
 _sig(H, "ntsm_hash64", C.c_uint64, [C.c_uint64, C.c_int])
@@ -115,6 +117,7 @@ _sig(SY, "ntsm_synth_short_fill_device", C.c_int, [C.POINTER(SynthShortParams), 
 _sig(SY, "ntsm_synth_long_fill_device", C.c_int, [C.POINTER(SynthLongParams), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                                   C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p])
 _sig(SY, "ntsm_synth_short_write_fastq", C.c_int, [C.POINTER(SynthShortParams), u8p, C.c_uint64, C.c_uint64, C.c_char_p])
+_sig(SY, "ntsm_synth_short_write_fastq_mt", C.c_int, [C.POINTER(SynthShortParams), u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint])
 _sig(SY, "ntsm_synth_long_write_fastq", C.c_int, [C.POINTER(SynthLongParams), u8p, u32p, C.c_uint64, C.c_uint64, C.c_char_p])
 
 KEYS_CANONICAL, KEYS_HASH64 = 0, 1
@@ -294,6 +297,9 @@ class Context:
     def set_kernel(self, variant):
         _chk(H.ntsm_set_kernel(self._h, int(variant)), "ntsm_set_kernel")
 
+    def set_armed_chunk(self, chunk_bytes):
+        _chk(H.ntsm_set_armed_chunk(self._h, int(chunk_bytes)), "ntsm_set_armed_chunk")
+
     def debug_stats(self):
         """dict(exotic_tiles, launches_tab, launches_k19, launches_generic) -- include/ntsm_hip.h ntsm_debug_stats"""
         out = np.zeros(8, dtype=np.uint64)
@@ -395,8 +401,9 @@ class SynthShort:
         if rc:
             raise NtsmError("device fill failed: %d" % rc)
 
-    def write_fastq(self, path, r0, n_reads):
-        rc = SY.ntsm_synth_short_write_fastq(C.byref(self.params), _p(self.windows, u8p), r0, n_reads, os.fsencode(path))
+    def write_fastq(self, path, r0, n_reads, threads=1):
+        """FASTQ of reads [r0, r0 + n_reads); threads > 1: the same bytes written by several threads (plain output)."""
+        rc = SY.ntsm_synth_short_write_fastq_mt(C.byref(self.params), _p(self.windows, u8p), r0, n_reads, os.fsencode(path), threads)
         if rc:
             raise NtsmError("write_fastq failed: %d" % rc)
 

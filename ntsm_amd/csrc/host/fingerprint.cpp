@@ -207,6 +207,10 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 					NTSM_KEYS_CANONICAL, m_maxCounts);
 		});
 	for (auto &t : mk) t.join();
+	/* several devices end with one RCCL SUM (fetchResults): bind the library now, so that a host without it hears
+	 * about it before the work, not after (the host-side sum of fetchResults takes over in that case) */
+	if (m_ctx.size() > 1 && ntsm_rccl_probe() != NTSM_OK)
+		std::cerr << "ntsmCount: warning: RCCL could not be loaded; the devices' counts will be summed on the host" << std::endl;
 	if (m_opt.phase_times)
 		std::cerr << "[phase] sites parsed " << std::chrono::duration<double>(tc1 - tc0).count() << " s, contexts (tables + upload) "
 		          << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc1).count() << " s" << std::endl;
@@ -332,6 +336,27 @@ void FingerPrint::fetchResults()
 	 * context reports the job-wide result -- SUM, not MAX: the per-site maxima are taken from the summed counts, which is
 	 * what one reference run over all reads computes (src/FingerPrint.hpp:281-294). */
 	int rc = m_ctx.size() > 1 ? ntsm_allreduce(m_ctx.data(), (int) m_ctx.size()) : NTSM_OK;
+	if (rc == NTSM_ERR_RCCL) {
+		/* RCCL missing or failing must not cost a finished run its result: every context still holds its own counts
+		 * (a failed ntsm_allreduce imports nothing), so they are summed here instead -- same SUM, over PCIe. */
+		std::cerr << "ntsmCount: RCCL unavailable (" << ntsm_strerror(rc) << "), summing the " << m_ctx.size()
+		          << " devices' counts on the host" << std::endl;
+		std::vector<uint64_t> part(m_counts.size());
+		rc = NTSM_OK;
+		for (size_t d = 0; d < m_ctx.size() && rc == 0; ++d) {
+			ntsm_totals t;
+			rc = ntsm_sync(m_ctx[d], &t);
+			if (rc == 0) rc = ntsm_counts(m_ctx[d], part.data());
+			if (rc) break;
+			for (size_t i = 0; i < part.size(); ++i) m_counts[i] += part[i];
+			m_totals.total_kmers += t.total_kmers;
+			m_totals.total_hits += t.total_hits;
+			m_totals.total_bases += t.total_bases;
+			m_totals.reads_consumed += t.reads_consumed;
+			m_totals.early_stop |= t.early_stop;
+		}
+		if (rc == 0) { m_fetched = true; return; }
+	}
 	if (rc == 0) rc = ntsm_sync(m_ctx[0], &m_totals);
 	if (rc == 0) rc = ntsm_counts(m_ctx[0], m_counts.data());
 	if (rc) {

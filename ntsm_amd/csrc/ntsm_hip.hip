@@ -258,7 +258,9 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(
 #define NTSM_STEP_POS 8                                /* positions between issuing the filter-block loads and testing them (8 or 4) */
 #endif
 constexpr int kFastC = NTSM_FAST_C;
+#ifdef NTSM_WITH_TAB
 constexpr int kListC = 128;                            /* list mode (tiles handed over by the tabulated kernel): always 32 KiB tiles */
+#endif
 constexpr int kQueueCap = 128;                         /* < 64 left over + one position's burst of <= 64 */
 
 /* LDS image of a tile: row r (C bytes) = stream bytes of thread r-1 (row 0 = the 32 bytes in front of the tile, in its
@@ -303,11 +305,19 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 			(int) (p.blk_bytes >> 4), 0x00020000 };
 	uint32_t nk_s = 0, nh = 0;                           /* nk_s: wave-uniform (scalar) count of valid windows */
 
+#ifdef NTSM_WITH_TAB
 	/* list mode: only the tiles the tabulated kernel handed over (tiles with bytes outside ACGTUNacgtun) */
 	const unsigned long long n_iter = p.use_list ? (unsigned long long) min(*p.exotic_count, p.exotic_cap) : p.n_tiles;
+#else
+	const unsigned long long n_iter = p.n_tiles;
+#endif
 	for (unsigned long long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+#ifdef NTSM_WITH_TAB
 		const unsigned long long ti = p.use_list ? (unsigned long long) p.exotic_list[it] : it;
 		if (ti >= p.n_tiles) continue;
+#else
+		const unsigned long long ti = it;
+#endif
 		const long long ts = p.t0 + (long long) (ti * (unsigned long long) (kThreads * C));
 		__syncthreads();
 		if (ts >= p.lo && ts + kThreads * C <= p.hi) {
@@ -641,7 +651,11 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 	}
 }
 
+#ifdef NTSM_WITH_TAB
+/* The tabulated k = 19 kernel + its look-up kernel: a measured negative result (7 % slower than the minimizer-blocked
+ * kernel), kept out of the default library; `make tab` builds ntsm_amd/libntsm_hip_tab.so with it. */
 #include "ntsm_tab_kernel.inc"
+#endif
 
 /* dense[i] = count of slot_of[i]; tail = totals */
 __global__ void ntsm_gather_kernel(const uint64_t *table, const uint32_t *slot_of, uint32_t n, unsigned long long *dense)
@@ -682,6 +696,7 @@ constexpr int kTileC = 128;                 /* stream bytes per thread and tile 
 #ifndef NTSM_TABLE_LOAD
 #define NTSM_TABLE_LOAD 0.4                    /* cuckoo key table: slots >= keys / load, power of two */
 #endif
+#ifdef NTSM_WITH_TAB
 #ifndef NTSM_TAB_SEG_TILES
 #define NTSM_TAB_SEG_TILES 16384
 #endif
@@ -692,6 +707,7 @@ constexpr int kTileC = 128;                 /* stream bytes per thread and tile 
 #define NTSM_TAB_TILES_PER_WG 1
 #endif
 constexpr uint64_t kTabSegTiles = NTSM_TAB_SEG_TILES;    /* tabulated path: 64 KiB tiles per launch segment (1 GiB); its look-up kernel runs beside the next segment */
+#endif
 constexpr int kTimingPool = 256;
 
 /* Process-wide pool of pinned host memory (ntsm_staging_pool): pinning costs ~0.4 ms/MiB and the driver serialises
@@ -810,6 +826,7 @@ struct ntsm_ctx {
 	uint32_t n_kmers = 0;
 	uint64_t max_hits = 0;
 	bool armed = false;                        /* the -m stop is active (max_hits != 0 at creation, or ntsm_set_max_hits) */
+	uint64_t armed_chunk_bytes = 256ull << 20;  /* stream bytes per chunk of an armed batch (ntsm_set_armed_chunk) */
 	uint64_t mask = 0;
 	/* device tables */
 	uint32_t *d_filter = nullptr, *d_slot_of = nullptr, *d_read_hits = nullptr;
@@ -825,6 +842,7 @@ struct ntsm_ctx {
 	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
 	uint32_t prefilter_log2 = 0;               /* log2(bits) */
 	NtsmBlockMap blk_map = { 1 };
+#ifdef NTSM_WITH_TAB
 	/* tabulated k = 19 path (ntsm_tab_kernel.inc) */
 	NtsmTabEntry *d_tab = nullptr;
 	uint4 *d_tblocks = nullptr;
@@ -841,8 +859,9 @@ struct ntsm_ctx {
 	std::vector<StreamBuf> sbuf;
 	int look_blocks = 0;                       /* tuning: look-up workgroups per CU (0 = 1) */
 	hipStream_t lstream = nullptr;             /* the look-up kernels of all launch streams run here, beside the next segment's scan */
+#endif
 	uint64_t n_launch[3] = { 0, 0, 0 };         /* count launches by kernel: tabulated, minimizer-blocked, generic */
-	int kernel_variant = 0;                    /* 0 auto (minimizer-blocked kernel when k == 19), 1 generic, 2 = 0, 3 tabulated k = 19 kernel */
+	int kernel_variant = 0;                    /* 0 auto (minimizer-blocked kernel for 13 <= k <= 31), 1 generic, 2 = 0, 3 tabulated k = 19 kernel (NTSM_WITH_TAB builds) */
 	std::vector<uint64_t> canon;               /* host copy of the canonical keys */
 	std::vector<uint32_t> slot_of;
 	/* batching */
@@ -1023,6 +1042,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 #endif
 		}
 	};
+#ifdef NTSM_WITH_TAB
 	std::vector<uint32_t> tblocks;
 	auto build_tblocks = [&]() {
 		/* k = 19, tabulated kernel: the same kind of filter (128-bit blocks, 4 bits per key, >= 12 bits per key, 3 MiB for
@@ -1059,6 +1079,9 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		}
 		c->tab_ok = ok;
 	};
+#else
+	auto build_tblocks = []() {};
+#endif
 	{
 		std::thread t1(build_filter), t2(build_blocks), t3(build_prefilter), t4(build_tblocks);
 		build_cuckoo();
@@ -1078,6 +1101,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		HIPCHK(hipMalloc(&c->d_blocks, blocks.size() * sizeof(uint32_t)));
 		HIPCHK(hipMemcpy(c->d_blocks, blocks.data(), blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
+#ifdef NTSM_WITH_TAB
 	if (c->d_tblocks) (void) hipFree(c->d_tblocks);
 	c->d_tblocks = nullptr;
 	if (!tblocks.empty()) {
@@ -1090,6 +1114,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			HIPCHK(hipMemcpy(c->d_tab, tab, sizeof tab, hipMemcpyHostToDevice));
 		}
 	}
+#endif
 	if (c->d_filter) (void) hipFree(c->d_filter);
 	if (c->d_keys) (void) hipFree(c->d_keys);
 	if (c->d_slot_of) (void) hipFree(c->d_slot_of);
@@ -1189,11 +1214,16 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k);
 	const bool fast = plan.mode >= 0 && c->d_blocks && c->kernel_variant != 1;
 	p.fk_k = plan.k; p.fk_m2 = 2 * plan.m; p.fk_a2 = 2 * plan.a;
+#ifdef NTSM_WITH_TAB
 	const bool tab = fast && !per_read && c->tab_ok && c->d_tblocks && c->kernel_variant == 3;
+#else
+	constexpr bool tab = false;
+#endif
 	if (fast && !tab) {                                     /* the minimizer-blocked kernels cut the stream into their own tiles */
 		const uint64_t ftile = (uint64_t) kThreads * kFastC;
 		p.n_tiles = (hi - (uint64_t) p.t0 + ftile - 1) / ftile;
 	}
+#ifdef NTSM_WITH_TAB
 	NtsmCountParams pt = p;                                 /* the tabulated kernel's view: 64 KiB tiles, segments of kTabSegTiles */
 	uint64_t tab_tiles = 0, tab_segs = 0;
 	ntsm_ctx::StreamBuf tab_sb = { nullptr, nullptr, 0, 0, nullptr, 0, { nullptr, nullptr }, { nullptr, nullptr } };
@@ -1260,6 +1290,7 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		p.exotic_cap = pt.exotic_cap;
 		p.use_list = 1;
 	}
+#endif
 	/* Grid: many more workgroups than fit on the chip at once (4 per CU), each walking ~8+ tiles.  A grid of
 	 * exactly the resident workgroups (static tile assignment) measured 11 % slower: the slowest CU sets the
 	 * finish time; with 32k-128k workgroups the dispatcher balances the load (measured plateau), while fewer
@@ -1283,6 +1314,7 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		}
 		HIPCHK(hipEventRecord(c->ev_a[ev], st));
 	}
+#ifdef NTSM_WITH_TAB
 	if (tab) {
 		/* the tabulated kernel counts every tile whose bytes are all ACGTUNacgtun and lists the others; the exact
 		 * minimizer-blocked kernel then walks that list (usually empty: it exits at once) */
@@ -1313,7 +1345,9 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		if (tab_segs > 1) HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[tab_segs & 1], 0));
 		hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kListC>), dim3((unsigned) std::min<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles)), dim3(kThreads), 0, st, p);
 		c->n_launch[0]++;
-	} else if (fast) {
+	} else
+#endif
+	if (fast) {
 		const dim3 g((unsigned) grid), b(kThreads);
 #define NTSM_MZ_CASE(M_) \
 		case 2 * M_: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, false, kFastC>), g, b, 0, st, p); break; \
@@ -1357,7 +1391,7 @@ int armed_batch(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t n_
 	/* The batch is walked in chunks of reads -- about 256 MB of stream each, at most 2^20 reads -- so that the work done is
 	 * proportional to what is consumed before the stop, not to the size of the batch. */
 	const uint64_t avg_len = std::max<uint64_t>(1, n_bytes / std::max<uint64_t>(1, n_reads));
-	static const uint64_t chunk_bytes = [] { const char *e = getenv("NTSM_ARMED_CHUNK_BYTES"); return e && atoll(e) > 0 ? (uint64_t) atoll(e) : (256ull << 20); }();   /* tests shrink it */
+	const uint64_t chunk_bytes = c->armed_chunk_bytes;      /* 256 MiB unless ntsm_set_armed_chunk changed it */
 	const uint64_t CH = std::min<uint64_t>(1ull << 20, std::max<uint64_t>(1024, chunk_bytes / avg_len));
 	const uint64_t n_chunks = (n_reads + CH - 1) / CH;
 	std::vector<uint64_t> bend(n_chunks);                 /* offset of the last terminator of every chunk */
@@ -1474,6 +1508,34 @@ int wait_slot(Slot &s)
 		s.busy = false;
 	}
 	return NTSM_OK;
+}
+
+/* RCCL is bound on first use: the library is 570 MB of code objects that the HIP runtime would otherwise map and
+ * register in every process that links it (~0.1 s and 1.4 GB of RSS for a single-GPU ntsmCount). */
+struct Rccl {
+	decltype(&ncclCommInitAll) CommInitAll = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	bool ok = false;
+	Rccl()
+	{
+		void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) return;
+		CommInitAll = (decltype(CommInitAll)) dlsym(h, "ncclCommInitAll");
+		GroupStart = (decltype(GroupStart)) dlsym(h, "ncclGroupStart");
+		GroupEnd = (decltype(GroupEnd)) dlsym(h, "ncclGroupEnd");
+		AllReduce = (decltype(AllReduce)) dlsym(h, "ncclAllReduce");
+		CommDestroy = (decltype(CommDestroy)) dlsym(h, "ncclCommDestroy");
+		ok = CommInitAll && GroupStart && GroupEnd && AllReduce && CommDestroy;
+	}
+};
+const Rccl &rccl_bind()
+{
+	static Rccl rccl;                                     /* thread-safe one-time binding */
+	return rccl;
 }
 
 } // namespace
@@ -1598,6 +1660,7 @@ void ntsm_destroy(ntsm_ctx *c)
 		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
 		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
 	}
+#ifdef NTSM_WITH_TAB
 	for (auto &b : c->sbuf) {
 		if (b.d_ctl) (void) hipFree(b.d_ctl);
 		if (b.d_queue) (void) hipFree(b.d_queue);
@@ -1607,7 +1670,10 @@ void ntsm_destroy(ntsm_ctx *c)
 		}
 	}
 	stream_put(c->device, c->lstream);
-	void *ptrs[] = { c->d_tab, c->d_tblocks, c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
+	if (c->d_tab) (void) hipFree(c->d_tab);
+	if (c->d_tblocks) (void) hipFree(c->d_tblocks);
+#endif
+	void *ptrs[] = { c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
 	for (void *p : ptrs) if (p) (void) hipFree(p);
 	delete c;
 }
@@ -1995,11 +2061,23 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 	return NTSM_OK;
 }
 
+int ntsm_set_armed_chunk(ntsm_ctx *c, uint64_t chunk_bytes)
+{
+	if (!c) return NTSM_ERR_ARG;
+	c->armed_chunk_bytes = chunk_bytes ? chunk_bytes : (256ull << 20);
+	return NTSM_OK;
+}
+
 void *ntsm_stream(ntsm_ctx *c) { return c ? (void *) c->rstream : nullptr; }
+
+int ntsm_rccl_probe(void) { return rccl_bind().ok ? NTSM_OK : NTSM_ERR_RCCL; }
 
 int ntsm_set_kernel(ntsm_ctx *c, int variant)
 {
 	if (!c || variant < 0 || variant > 3) return NTSM_ERR_ARG;
+#ifndef NTSM_WITH_TAB
+	if (variant == 3) return NTSM_ERR_ARG;                 /* the tabulated kernel is not part of this build (make tab) */
+#endif
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
 	c->kernel_variant = variant;
@@ -2013,11 +2091,13 @@ int ntsm_debug_stats(ntsm_ctx *c, uint64_t out[8])
 	if (rc) return rc;
 	HIPCHK(hipDeviceSynchronize());
 	uint64_t exotic = 0;
+#ifdef NTSM_WITH_TAB
 	for (auto &b : c->sbuf) {
 		uint32_t seen = 0;
 		if (b.d_ctl) HIPCHK(hipMemcpy(&seen, b.d_ctl + 1 + 2 * b.seg_cap, sizeof seen, hipMemcpyDeviceToHost));
 		exotic += seen;
 	}
+#endif
 	out[0] = exotic;
 	out[1] = c->n_launch[0];
 	out[2] = c->n_launch[1];
@@ -2041,29 +2121,7 @@ int ntsm_allreduce(ntsm_ctx *const *ctxs, int n)
 		if (rc) return rc;
 	}
 	if (n > 1) {
-		/* RCCL is bound on first use: the library is 570 MB of code objects that the HIP runtime would otherwise
-		 * map and register in every process that links it (≈0.1 s and 1.4 GB of RSS for a single-GPU ntsmCount). */
-		struct Rccl {
-			decltype(&ncclCommInitAll) CommInitAll = nullptr;
-			decltype(&ncclGroupStart) GroupStart = nullptr;
-			decltype(&ncclGroupEnd) GroupEnd = nullptr;
-			decltype(&ncclAllReduce) AllReduce = nullptr;
-			decltype(&ncclCommDestroy) CommDestroy = nullptr;
-			bool ok = false;
-			Rccl()
-			{
-				void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-				if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-				if (!h) return;
-				CommInitAll = (decltype(CommInitAll)) dlsym(h, "ncclCommInitAll");
-				GroupStart = (decltype(GroupStart)) dlsym(h, "ncclGroupStart");
-				GroupEnd = (decltype(GroupEnd)) dlsym(h, "ncclGroupEnd");
-				AllReduce = (decltype(AllReduce)) dlsym(h, "ncclAllReduce");
-				CommDestroy = (decltype(CommDestroy)) dlsym(h, "ncclCommDestroy");
-				ok = CommInitAll && GroupStart && GroupEnd && AllReduce && CommDestroy;
-			}
-		};
-		static Rccl rccl;                                     /* thread-safe one-time binding */
+		const Rccl &rccl = rccl_bind();
 		if (!rccl.ok) return NTSM_ERR_RCCL;
 		std::vector<int> devs(n);
 		for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;

@@ -4,12 +4,16 @@
  */
 #include "../../include/ntsm_synth.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 namespace {
@@ -256,6 +260,70 @@ int ntsm_synth_short_write_fastq(const ntsm_synth_short *p, const uint8_t *windo
 		out.write(rec.data(), rec.size());
 	}
 	out.close();
+	return 0;
+}
+
+/* The same bytes as ntsm_synth_short_write_fastq (plain output only), written by n_threads threads: the record of read
+ * r is 2 + digits(r) + 1 + L + 3 + L + 1 bytes, so every thread knows where its slice of reads starts in the file and
+ * writes it there with pwrite().  For the multi-gigabyte inputs of the end-to-end CLI measurements. */
+int ntsm_synth_short_write_fastq_mt(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
+		uint64_t n_reads, const char *path, unsigned n_threads)
+{
+	size_t plen = strlen(path);
+	if (n_threads <= 1 || (plen > 3 && !strcmp(path + plen - 3, ".gz")))
+		return ntsm_synth_short_write_fastq(p, windows, r0, n_reads, path);
+	auto digits_sum = [](uint64_t a, uint64_t b) {             /* sum of the decimal lengths of a .. b-1 */
+		uint64_t s = 0, lo = 1, d = 1;
+		for (; d <= 20; ++d) {
+			const uint64_t hi = d == 20 ? UINT64_MAX : lo * 10;   /* numbers with d digits: [lo, hi), and 0 counts as one digit */
+			const uint64_t x = std::max(a, d == 1 ? 0 : lo), y = std::min(b, hi);
+			if (y > x) s += (y - x) * d;
+			if (d == 20 || hi > b) break;
+			lo = hi;
+		}
+		return s;
+	};
+	const uint64_t L = p->read_len, fixed = 2 + 1 + L + 3 + L + 1;
+	const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	if (fd < 0) return -2;
+	const uint64_t total = n_reads * fixed + digits_sum(r0, r0 + n_reads);
+	if (ftruncate(fd, (off_t) total) != 0) { close(fd); return -2; }
+	std::vector<std::thread> pool;
+	std::vector<int> rcs(n_threads, 0);
+	for (unsigned t = 0; t < n_threads; ++t)
+		pool.emplace_back([&, t]() {
+			const uint64_t a = r0 + n_reads * t / n_threads, b = r0 + n_reads * (t + 1) / n_threads;
+			uint64_t off = (a - r0) * fixed + digits_sum(r0, a);
+			const uint64_t stride = L + 1;
+			std::vector<uint8_t> seq(stride);
+			std::string buf, qual(L, 'I');
+			buf.reserve((8u << 20) + 2 * fixed);
+			auto flush = [&]() {
+				size_t done = 0;
+				while (done < buf.size()) {
+					const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t) (off + done));
+					if (w <= 0) { rcs[t] = -3; return; }
+					done += (size_t) w;
+				}
+				off += buf.size();
+				buf.clear();
+			};
+			for (uint64_t r = a; r < b && rcs[t] == 0; ++r) {
+				ntsm_synth_short_fill_host(p, windows, r * stride, L, seq.data());
+				buf += "@r";
+				buf += std::to_string(r);
+				buf += '\n';
+				buf.append((const char *) seq.data(), L);
+				buf += "\n+\n";
+				buf += qual;
+				buf += '\n';
+				if (buf.size() >= (8u << 20)) flush();
+			}
+			if (rcs[t] == 0) flush();
+		});
+	for (auto &th : pool) th.join();
+	close(fd);
+	for (int rc : rcs) if (rc) return rc;
 	return 0;
 }
 

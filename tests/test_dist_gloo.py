@@ -167,3 +167,53 @@ def test_ordered_early_stop_across_ranks_equals_single_run(built):
         assert stopped and stop_rank is not None
         assert np.array_equal(merged[:-4].astype(np.uint64), ref.kmers()[2])
         assert list(merged[-4:]) == [ref.total_kmers, ref.total_hits, ref.total_bases, ref.reads_processed]
+
+
+def test_bench_self_launch_spawns_one_child_per_rank():
+    """`python bench.py --gpus N` with no launcher starts N fresh child processes itself (before anything in the parent
+    touches the GPU) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; --dry-launch makes every child print its rank
+    environment and leave before the first GPU call, so the real spawn path runs here on the CPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "2", "--dry-launch"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    rows = sorted((json.loads(l) for l in p.stdout.decode().split("\n") if l.startswith("{")), key=lambda r: r["rank"])
+    assert [r["rank"] for r in rows] == [0, 1, 2] and [r["local_rank"] for r in rows] == [0, 1, 2]
+    assert all(r["world_size"] == 3 and r["gpus"] == 3 and r["master_addr"] == "127.0.0.1" for r in rows)
+    assert len({r["master_port"] for r in rows}) == 1 and len({r["pid"] for r in rows}) == 3 and len({r["ppid"] for r in rows}) == 1
+    # a launcher (torch.distributed.run) whose world size differs from --gpus is refused: no rank runs, no JSON line
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert q.returncode != 0 and q.stdout == b"" and b"refusing" in q.stderr
+    # more GPUs than the node has (none here): refused before any child is started
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode != 0 and r.stdout == b"" and b"refusing" in r.stderr
+    # under torch.distributed.run the ranks come from the launcher and bench.py does not spawn again
+    port = 29700 + os.getpid() % 200
+    t = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert t.returncode == 0, t.stderr.decode()[-800:]
+    rows = [json.loads(l) for l in t.stdout.decode().split("\n") if l.startswith("{")]
+    assert sorted(r["rank"] for r in rows) == [0, 1] and all(r["world_size"] == 2 for r in rows)
+
+
+def test_rccl_binding_resolves_every_symbol_ntsm_allreduce_calls(built):
+    """ntsm_allreduce binds RCCL with dlopen on first use (ntsm_hip.hip: struct Rccl).  No box with two GPUs has run it
+    yet, so the binding itself is checked here: ntsm_rccl_probe() performs exactly that dlopen + five dlsym calls and
+    needs no GPU; and the five names exist in the RCCL this image ships."""
+    import ctypes
+    import ntsm_amd
+    assert ntsm_amd.capi.H.ntsm_rccl_probe() == 0
+    lib = None
+    for name in ("librccl.so.1", "librccl.so"):
+        try:
+            lib = ctypes.CDLL(name)
+            break
+        except OSError:
+            pass
+    assert lib is not None
+    for sym in ("ncclCommInitAll", "ncclGroupStart", "ncclGroupEnd", "ncclAllReduce", "ncclCommDestroy"):
+        assert hasattr(lib, sym), sym

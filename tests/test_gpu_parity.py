@@ -140,8 +140,8 @@ def test_random_reads_vs_oracle_n10(nt, n10):
     fp = OracleFP(path)
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)   # one long "read": terminators reset windows
     _, _, ocnt = fp.kmers()
-    # kernel variants (0 = minimizer-blocked fast path, 1 = generic, 3 = tabulated) and filter sizes must all agree
-    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (3, 0), (3, 20), (3, 25), (3, 124)):
+    # kernel variants (0 = minimizer-blocked fast path, 1 = generic) and filter sizes must all agree
+    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (0, 124)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         if flog:
@@ -424,7 +424,7 @@ def test_large_site_set_regime(nt, tmp_path):
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)
     want = fp.kmers()[2]
     assert fp.total_hits > 100_000
-    for variant, flog in ((0, 0), (1, 0), (3, 0), (0, 123), (3, 123)):
+    for variant, flog in ((0, 0), (1, 0), (0, 123)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         if flog:
@@ -599,12 +599,32 @@ def test_bench_two_ranks_over_rccl(nt):
     the merged totals of both shards."""
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--reads", "2e6", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                        "--reads", "2e6", "--no-cpu-baseline", "--other-configs", "none"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert "RCCL SUM" in line["config"]["parallelism"]
+
+
+def test_bench_gpus_flag_launches_or_refuses(nt):
+    """`python bench.py --gpus N` without a launcher (the form the driver uses at N = 1 and may use at N > 1) starts N ranks
+    itself.  On a box with fewer than N devices it must end non-zero with a message and NO JSON line -- never an N = 1 result
+    under an N > 1 request; where N devices exist the self-launched job must report n_gpus = N."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "2e6",
+           "--no-cpu-baseline", "--other-configs", "none"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    out = [l for l in p.stdout.decode().split("\n") if l.startswith("{")]
+    if _n_gpus() < 2:
+        assert p.returncode != 0 and out == [] and b"refusing" in p.stderr, (p.returncode, p.stdout[-300:], p.stderr[-500:])
+    else:
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        line = json.loads(out[-1])
+        assert len(out) == 1 and line["n_gpus"] == 2 and "self-spawned" in line["config"]["launched_by"]
+    # a launcher whose world size differs from --gpus is refused as well
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "2e6"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert q.returncode != 0 and b"{" not in q.stdout
 
 
 def test_bench_rccl_path_on_one_rank(nt):
@@ -613,17 +633,17 @@ def test_bench_rccl_path_on_one_rank(nt):
     the barriers and the MAX over ranks.  Merging a vector with itself over one rank must leave the totals of a plain run."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NTSM_FORCE_DIST="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "2e6", "--no-cpu-baseline"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "2e6", "--no-cpu-baseline", "--other-configs", "none"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads([l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1])
-    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "2e6", "--no-cpu-baseline"],
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "2e6", "--no-cpu-baseline", "--other-configs", "none"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert q.returncode == 0, q.stderr.decode()[-2000:]
     e = json.loads([l for l in q.stdout.decode().split("\n") if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["check"]["total_kmers_per_step"] == e["check"]["total_kmers_per_step"] and d["check"]["total_hits_per_step"] == e["check"]["total_hits_per_step"]
-    assert e["check"]["equals_sum_of_pieces_below_2GiB"] is True
+    assert e["check"]["equals_generic_kernel_sum_of_pieces_below_2GiB"] is True
 
 
 def test_early_stop_across_chunks(nt, n10):
@@ -660,8 +680,8 @@ def test_early_stop_across_chunks(nt, n10):
 def test_early_stop_when_a_long_optimistic_span_crosses(n10, tmp_path):
     """The armed path counts optimistically in spans of chunks sized from the hit rate so far.  A stream whose first 60 %
     has no site k-mers makes that rate zero, so the second span covers everything that is left, crosses inside the dense
-    part, is taken out again and walked chunk by chunk down to the crossing read.  Small chunks (NTSM_ARMED_CHUNK_BYTES)
-    make this a 30-chunk batch; the run is a subprocess because the library reads the knob once."""
+    part, is taken out again and walked chunk by chunk down to the crossing read.  Small chunks (ntsm_set_armed_chunk)
+    make this a 30-chunk batch."""
     s, sites, path = n10
     code = r"""
 import sys, numpy as np
@@ -679,9 +699,10 @@ full = OracleFP(path); full.process_flat(bases, ends)
 thr = int(full.total_hits * 0.3)
 fp = OracleFP(path, cov=2.0 * (thr + 0.5) / len(sites.keys)); assert fp.max_hits == thr
 fp.process_flat(bases, ends); assert fp.early_term and fp.reads_processed > n0 + 1000
-for variant in (0, 3, 1):                                # minimizer-blocked, tabulated (its spans and undo passes), generic
+for variant in (0, 1):                                   # minimizer-blocked, generic
     ctx = nt.Context(sites.keys, max_hits=thr)
     ctx.set_kernel(variant)
+    ctx.set_armed_chunk(1 << 20)
     ctx.submit(bases, ends)
     t = ctx.sync()
     st = ctx.debug_stats()
@@ -692,7 +713,7 @@ for variant in (0, 3, 1):                                # minimizer-blocked, ta
     ctx.close()
 print("ok", t.reads_consumed)
 """ % (ROOT, os.path.join(ROOT, "tests"), path)
-    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, NTSM_ARMED_CHUNK_BYTES=str(1 << 20)))
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
 
 
@@ -937,67 +958,37 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
         fp.L.ntsm_oracle_fp_insert_count(fp.h, buf.tobytes(), n)
         ends = np.array([n], dtype=np.uint64)
         flat = np.concatenate([buf, np.frombuffer(b"N", dtype=np.uint8)])
-        for variant in (0, 1) + ((3,) if k == 19 else ()):
+        for variant in (0, 1):
             ctx = nt.Context(sites.keys, k=k)
             ctx.set_kernel(variant)
             ctx.submit(flat, ends)
             t = ctx.sync()
             assert np.array_equal(ctx.counts(), fp.kmers()[2]), (k, variant)
             assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, n), (k, variant)
-            if variant == 3:          # the tabulated kernel only takes ACGTUNacgtun: every 64 KiB tile here goes to the exact kernel
-                st = ctx.debug_stats()
-                assert st["launches_tab"] == 1 and st["exotic_tiles"] == -(-(n + 1) // 65536), st
             ctx.close()
         assert fp.total_hits > 100
 
 
 def test_tabulated_kernel_paths(nt, n10, tmp_path):
-    """The tabulated k = 19 kernel (ntsm_set_kernel 3) on the inputs that take its special paths, against the oracle:
-    (a) reads made of site sequence -- far more windows pass the filter than a wave's queue slot holds, so they are looked
-    up in line; (b) a clean stream with a few foreign bytes -- only the tiles that hold them go to the exact kernel;
-    (c) lowercase / U / N-rich input stays on the tabulated kernel; (d) several launches reuse the per-stream buffers."""
+    """The tabulated k = 19 kernel is a measured negative result that lives behind -DNTSM_WITH_TAB: the default library
+    refuses ntsm_set_kernel(ctx, 3); `make tab` builds ntsm_amd/libntsm_hip_tab.so with it, and tests/tab_kernel_check.py
+    (a subprocess, because the library is chosen when ntsm_amd is imported) runs it against the oracle on the inputs that
+    take its special paths."""
     s, sites, path = n10
-    rng = np.random.default_rng(7)
-    win = s.windows.reshape(-1, 32)[:, :31]
-    # (a) 40k site windows back to back, each followed by 'N'
-    pick = np.frombuffer(b"ACGT", dtype=np.uint8)[win[rng.integers(0, win.shape[0], 40_000)]]   # windows are stored as codes 0..3
-    dense = np.concatenate([pick, np.full((pick.shape[0], 1), ord("N"), np.uint8)], axis=1).reshape(-1)
-    ends = (np.arange(pick.shape[0], dtype=np.uint64) * np.uint64(32)) + np.uint64(31)
-    # (b)+(c) 6000 seeded reads, some lowercase, some T -> U, extra N, and three foreign bytes far apart
-    n = 6000
-    clean = s.host_bytes(0, n).copy()
-    low = rng.random(clean.size) < 0.3
-    clean[low & (clean != ord("N"))] |= 0x20
-    tmask = (clean == ord("T")) & (rng.random(clean.size) < 0.5)
-    clean[tmask] = ord("U")
-    clean[rng.integers(0, clean.size, 200)] = ord("n")
-    for r in range(n):                                   # keep the terminators
-        clean[r * s.stride + s.read_len] = ord("N")
-    foreign = clean.copy()
-    for at, b in ((1000, ord("R")), (70_000, 0), (500_000, ord("-"))):
-        foreign[at] = b
-    cends = s.read_end(n)
-    for name, buf, e, exotic in (("dense", dense, ends, 0), ("clean", clean, cends, 0), ("foreign", foreign, cends, 3)):
-        fp = OracleFP(path)
-        fp.process_flat(buf, e)
-        ctx = nt.Context(sites.keys)
+    ctx = nt.Context(sites.keys)
+    with pytest.raises(nt.NtsmError):
         ctx.set_kernel(3)
-        for rep in range(2):                             # second launch: buffers reused, counts double
-            ctx.submit(buf, e)
-        t = ctx.sync()
-        st = ctx.debug_stats()
-        assert np.array_equal(ctx.counts(), 2 * fp.kmers()[2]), name
-        assert (t.total_kmers, t.total_hits, t.total_bases) == (2 * fp.total_kmers, 2 * fp.total_hits, 2 * fp.total_bases), name
-        assert st["launches_tab"] == 2 and st["exotic_tiles"] == 2 * exotic, (name, st)
-        if name == "dense":
-            assert fp.total_hits > 0.3 * fp.total_kmers and st["queued_windows"] < fp.total_hits   # most were looked up in line
-        ctx.close()
+    ctx.close()
+    subprocess.run(["make", "-C", ROOT, "tab"], check=True, stdout=subprocess.DEVNULL)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tab_kernel_check.py"), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, NTSM_HIP_LIB="libntsm_hip_tab.so"))
+    assert p.returncode == 0 and p.stdout.strip().endswith(b"ok"), p.stderr.decode()[-2000:]
 
 
 def test_resident_stream_beyond_4gib(nt, n10):
     """A resident stream of 6e7 reads (9.06 GB: byte offsets far beyond 2^32 inside ONE launch): counts of the whole
     buffer == the sum over pieces of < 2 GiB counted separately (each piece re-based, so its offsets are small), for the
-    default and the tabulated kernel; and a window cut from beyond byte 2^32 equals the oracle on the same reads."""
+    default kernel; and a window cut from beyond byte 2^32 equals the oracle on the same reads."""
     import torch
     s, sites, path = n10
     dev = torch.device("cuda:0")
@@ -1015,7 +1006,7 @@ def test_resident_stream_beyond_4gib(nt, n10):
     cr = ref.counts()
     ref.close()
     assert tr.total_bases == n * s.read_len and tr.total_hits > 1_000_000
-    for variant in (0, 3):
+    for variant in (0,):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         ctx.count_resident(d.data_ptr(), n * s.stride, 0, n)
@@ -1072,7 +1063,8 @@ def test_bench_contract_line(nt):
     """bench.py at a small size: exactly one JSON line with the contract's keys (metric/value/unit/..., roofline,
     cpu_baseline from the CPU reference or its port), and the per-step totals it reports are the oracle-checked ones
     scaled: value = bases / time, frac = achieved / peak."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2e6", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2e6", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000",
+                        "--long-reads", "2e4", "--stress-sites", "2e4", "--stress-reads", "1e6", "--e2e-reads", "2e5", "--e2e-threads", "4"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()[-1500:]
     lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
@@ -1088,3 +1080,11 @@ def test_bench_contract_line(nt):
     assert abs(d["value"] - 2e6 * 150 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == "bases/s" and 1e6 < c["value"] < 1e9
+    assert d["check"]["equals_generic_kernel_sum_of_pieces_below_2GiB"] is True
+    # the secondary configurations ride on the same line, each with its own check (configs[2], configs[4], CLI)
+    o = d["other_configs"]
+    assert set(o) == {"long", "stress", "e2e_cli"} and not any("error" in v for v in o.values()), o
+    assert o["long"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["long"]["gbases_per_s"] > 0 and 0 < o["long"]["roofline_frac"] < 1
+    assert o["long"]["m10"]["early_stop"] in (True, False) and o["long"]["m10"]["stop_read"] <= o["long"]["reads"]
+    assert o["stress"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["stress"]["gbases_per_s"] > 0
+    assert o["e2e_cli"]["check"]["counts_txt_equals_resident_path"] and o["e2e_cli"]["wall_s"] > 0 and len(o["e2e_cli"]["counts_sha256"]) == 64

@@ -10,20 +10,22 @@ so half of the stream bytes are added back; the random 4/8/16-byte filter and ta
 import collections, csv, glob, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["ntsm_amd/csrc/ntsm_hip.hip", "ntsm_amd/csrc/ntsm_device.h", "ntsm_amd/csrc/ntsm_tab_kernel.inc"]
+KERNEL_SOURCES = ["ntsm_amd/csrc/ntsm_hip.hip", "ntsm_amd/csrc/ntsm_device.h"]
 
 
 def kernel_source_sha16():
-    """SHA-256 over the device code: ntsm_device.h, the tabulated kernel's include and the part of ntsm_hip.hip in front of
-    its ' * Host code' banner (edits to the host half of that file do not change any kernel)."""
+    """SHA-256 over everything that decides what runs on the device and how it is launched: the whole of ntsm_hip.hip
+    (kernels AND the launch code: grid heuristic, tile sizes), ntsm_device.h and the build flags of the library
+    (Makefile's HIPFLAGS line and the libntsm_hip.so recipe, where -D overrides of the build parameters would sit)."""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        data = open(os.path.join(ROOT, f), "rb").read()
-        if f.endswith("ntsm_hip.hip"):
-            cut = data.find(b"\n * Host code")
-            assert cut > 0, "ntsm_hip.hip: ' * Host code' banner not found"
-            data = data[:cut]
-        h.update(data)
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    mk = open(os.path.join(ROOT, "Makefile")).read().split("\n")
+    for i, line in enumerate(mk):
+        if line.startswith("HIPFLAGS") or line.startswith("ntsm_amd/libntsm_hip.so:"):
+            h.update(line.encode())
+            if line.startswith("ntsm_amd/libntsm_hip.so:") and i + 1 < len(mk):
+                h.update(mk[i + 1].encode())
     return h.hexdigest()[:16]
 
 
@@ -38,7 +40,7 @@ def main():
         for name, d in acc.items():
             vals = sorted(d.values())
             per[name] = vals[len(vals) // 2]                     # median dispatch (all launches do the same work)
-    stream = bases * 151.0 / 150.0
+    stream = bases * 151.0 / 150.0 if len(sys.argv) < 5 else float(sys.argv[4])   # optional 4th argument: stream bytes per launch
     fetch_raw, write = per["FETCH_SIZE"] * 1024.0, per["WRITE_SIZE"] * 1024.0
     fetch = fetch_raw + 0.5 * stream
     cycles = per["GRBM_GUI_ACTIVE"] / 8.0                        # summed over the 8 XCDs
@@ -53,6 +55,9 @@ def main():
         "valu_insts_per_position": per["SQ_INSTS_VALU"] / (stream / 64.0) if per.get("SQ_INSTS_VALU") else None,
         "valu_busy_frac": per["SQ_INSTS_VALU"] * 4.2 / (1024.0 * cycles) if per.get("SQ_INSTS_VALU") and cycles else None,
         "valu_busy_note": "SQ_INSTS_VALU x 4.2 cycles per wave64 instruction (profiles/r02_microbench/valu_rate.txt) / (1024 SIMDs x GRBM_GUI_ACTIVE/8)",
+        "l2_requests_per_base": per["TCC_REQ_sum"] / bases if per.get("TCC_REQ_sum") else None,
+        "l2_misses_per_base": per["TCC_MISS_sum"] / bases if per.get("TCC_MISS_sum") else None,
+        "fabric_read_requests_per_base": per["TCC_EA0_RDREQ_sum"] / bases if per.get("TCC_EA0_RDREQ_sum") else None,
         "l2_requests_per_launch": per.get("TCC_REQ_sum"), "l2_misses_per_launch": per.get("TCC_MISS_sum"),
         "l2_request_rate_frac_of_cap": (per["TCC_REQ_sum"] / (cycles / 2.4e9) / 266e9) if per.get("TCC_REQ_sum") and cycles else None,
         "l2_cap_note": "cap = 266 G requests/s whatever the request width (profiles/r02_microbench/l2_policy.txt); time from GRBM_GUI_ACTIVE at 2.4 GHz",
