@@ -159,21 +159,30 @@ int ntsm_reset(ntsm_ctx *ctx);
  * it runs on; get returns the number of launches and the sum of their durations since `on`. */
 int ntsm_set_timing(ntsm_ctx *ctx, int on);
 int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
-/* Tuning knobs (0 = automatic): log2 of filter bits (rebuilds the tables: counts and totals restart from zero),
- * grid blocks.  For profiling experiments. */
+/* Tuning knobs (0 = automatic): log2 of filter bits (rebuilds the tables: counts and totals restart from zero; 100 + v =
+ * 3 * 2^v bits; 200 + v / 250 + v = size of the two-level path's minimizer Bloom, 2^v / 3 * 2^v bits), grid blocks.
+ * For profiling experiments. */
 int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
 /* An armed (-m) batch is walked in chunks of about chunk_bytes of stream (at most 2^20 reads, at least 1024) so that the work
  * is proportional to what is consumed before the stop; 0 = the default (256 MiB).  Any value gives the same result. */
 int ntsm_set_armed_chunk(ntsm_ctx *ctx, uint64_t chunk_bytes);
-/* Kernel choice: 0 = automatic (13 <= k <= 31: the minimizer-blocked kernel; other k: the generic kernel), 1 = always the
- * generic kernel, 2 = same as 0.  Both kernels give identical results.  3 = the tabulated k = 19 kernel, a measured
- * negative result (7 % slower) that only exists in -DNTSM_WITH_TAB builds (`make tab`:
- * ntsm_amd/libntsm_hip_tab.so); the default library answers NTSM_ERR_ARG. */
+/* Kernel choice.  All choices give identical results.
+ *   0  automatic: 13 <= k <= 31 the minimizer-blocked kernel, other k the generic kernel; k = 19 with a site set whose
+ *      blocked filter is well out of the L2 (more than ~3.1 M k-mers) takes the two-level form of the kernel: 14-mer
+ *      minimizers and a Bloom word over the distinct site minimizers in front of the block
+ *   1  always the generic kernel
+ *   2  the minimizer-blocked kernel, one level, whatever the size of the set
+ *   4  k = 19 only: the two-level form, whatever the size of the set
+ *   3  the tabulated k = 19 kernel, a measured negative result (7 % slower) that only exists in
+ *      -DNTSM_WITH_TAB builds (`make tab`: ntsm_amd/libntsm_hip_tab.so); the default library answers NTSM_ERR_ARG.
+ * One-level and two-level filters are different tables: a call that changes the level rebuilds them, and counts and
+ * totals restart from zero (like ntsm_set_tuning with a filter size). */
 int ntsm_set_kernel(ntsm_ctx *ctx, int variant);
 /* Introspection for tests and profiles (implies a sync): out[0] = 64 KiB tiles the tabulated kernel handed to the
  * exact kernel because they hold bytes outside ACGTUNacgtun, out[1..3] = count launches by kernel
  * (tabulated, minimizer-blocked, generic), out[4] = windows that passed the tabulated kernel's first-level filter and
- * were queued for the look-up kernel (since creation or the last ntsm_reset), out[5..7] = 0 (reserved). */
+ * were queued for the look-up kernel (since creation or the last ntsm_reset), out[5] = 1 when the tables are the
+ * two-level ones, out[6] = words of the minimizer Bloom, out[7] = distinct site minimizers (two-level tables). */
 int ntsm_debug_stats(ntsm_ctx *ctx, uint64_t out[8]);
 /* The HIP stream (hipStream_t) ntsm_count_resident launches on. */
 void *ntsm_stream(ntsm_ctx *ctx);

@@ -48,6 +48,15 @@ NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC
 #endif
 #define NTSM_FAST_W (NTSM_FAST_K - NTSM_FAST_M + 1)
 #define NTSM_MMER_MASK ((1u << (2 * NTSM_FAST_M)) - 1u)
+/* Large site sets (the blocked filter no longer fits the 4 MiB L2): k = 19 switches to 14-mer
+ * minimizers (6 candidates) and puts a one-word Bloom filter over the DISTINCT SITE MINIMIZERS in front of the blocked
+ * filter: a minimizer run first asks the L2-resident Bloom word, and only runs that pass (site minimizers + false
+ * positives: 30 % at 16 M keys) go on to their 128-bit block in the Infinity Cache.  12-mers cannot do this: with 16 M
+ * site k-mers 80 % of all read minimizers ARE site minimizers (tools/sim_two_level.cpp). */
+#ifndef NTSM_TWO_M
+#define NTSM_TWO_M 14
+#endif
+#define NTSM_TWO_W (NTSM_FAST_K - NTSM_TWO_M + 1)
 
 /* The same filter for other k (13 <= k <= 31, k != 19): 12-mers throughout; what varies is which of them are minimizer
  * candidates.  The candidate set must map onto itself under reverse complement, i.e. be symmetric in the k-mer:
@@ -56,10 +65,11 @@ NTSM_DHD uint32_t ntsm_h2(uint32_t folded) { return (folded ^ 0x5BD1E995u) * 0xC
  *   k <  19   all k - 11 of them (2 .. 7)
  * so the sliding minimum runs over 2 .. 9 order hashes, computed `a` positions behind the newest base. */
 struct NtsmFastPlan { int mode; uint32_t k, m, w, a; };      /* mode: -1 no fast path, 0 the k = 19 kernel, else w (the kernel's KMODE) */
-NTSM_DHD NtsmFastPlan ntsm_fast_plan(uint32_t k)
+NTSM_DHD NtsmFastPlan ntsm_fast_plan(uint32_t k, bool two_level = false)
 {
 	NtsmFastPlan pl = { -1, k, 0u, 0u, 0u };
-	if (k == NTSM_FAST_K) { pl.mode = 0; pl.m = NTSM_FAST_M; pl.w = NTSM_FAST_W; }
+	if (k == NTSM_FAST_K && two_level) { pl.mode = 0; pl.m = NTSM_TWO_M; pl.w = NTSM_TWO_W; }
+	else if (k == NTSM_FAST_K) { pl.mode = 0; pl.m = NTSM_FAST_M; pl.w = NTSM_FAST_W; }
 	else if (k >= 19 && k <= 31) { pl.m = 12; pl.w = (k & 1u) ? 8u : 9u; pl.a = (k - 12u - (pl.w - 1u)) / 2u; pl.mode = (int) pl.w; }
 	else if (k >= 13 && k < 19) { pl.m = 12; pl.w = k - 11u; pl.mode = (int) pl.w; }
 	return pl;
@@ -86,20 +96,31 @@ NTSM_DHD uint32_t ntsm_mmer_hash(uint32_t canon)
 	return (uint32_t) ((uint64_t) (canon & 0xFFFFFFu) * 0x9E3779u);
 #endif
 }
+/* the same for m-mers of more than 12 bases (canonical code up to 32 bits): full 32-bit multiply, a bijection */
+NTSM_DHD uint32_t ntsm_mmer_hash_wide(uint32_t canon) { return canon * 0x9E3779B1u; }
+NTSM_DHD uint32_t ntsm_mmer_hash_m(uint32_t canon, uint32_t m) { return m <= 12u ? ntsm_mmer_hash(canon) : ntsm_mmer_hash_wide(canon); }
 /* Index of the 128-bit filter block of a minimizer value: h = mz * odd constant (full 32-bit multiply: the top bits of
  * a minimum are small; the multiply carries every bit of it into the top bits), then the multiply-high range reduction of h onto n_blocks, power of two or
  * not.  Two instructions (v_mul_lo_u32, v_mul_hi_u32); the kernel hands the index to a buffer load whose descriptor
  * has a 16-byte stride (idxen), so the byte offset costs nothing. */
 struct NtsmBlockMap { uint32_t n_blocks; };
-NTSM_DHD uint32_t ntsm_block_idx(uint32_t mz, NtsmBlockMap m)
+NTSM_DHD uint32_t ntsm_block_hash(uint32_t mz) { return mz * 0x9E3779B1u; }
+NTSM_DHD uint32_t ntsm_range(uint32_t h, uint32_t n)       /* multiply-high range reduction of a 32-bit hash onto [0, n) */
 {
-	const uint32_t h = mz * 0x9E3779B1u;
 #if defined(__HIP_DEVICE_COMPILE__)
-	return __umulhi(h, m.n_blocks);
+	return __umulhi(h, n);
 #else
-	return (uint32_t) (((uint64_t) h * m.n_blocks) >> 32);
+	return (uint32_t) (((uint64_t) h * n) >> 32);
 #endif
 }
+NTSM_DHD uint32_t ntsm_block_idx(uint32_t mz, NtsmBlockMap m) { return ntsm_range(ntsm_block_hash(mz), m.n_blocks); }
+/* Two-level path: the Bloom word of a minimizer is ntsm_range(h, n_words) with the same h = ntsm_block_hash(mz) that picks
+ * its block; the two bits it sets / tests in that word are 31 - (h & 31) and 31 - ((h >> 8) & 31) -- byte-aligned fields
+ * of the LOW half of h (the word index uses the top bits), taken by the kernel with byte selects and tested in the sign
+ * position like the block bits.  Measured on the 1 M-site set: 0.087 second-level requests per k-mer with a 3 MiB
+ * Bloom, against 0.078 for bits from a second multiply and 0.229 without the Bloom (tools/sim_two_level.cpp). */
+#define NTSM_BLOOM_BIT0(h) (31u - ((h) & 31u))
+#define NTSM_BLOOM_BIT1(h) (31u - (((h) >> 8) & 31u))
 /* Four filter bits per site k-mer, one in each 32-bit word of its 128-bit block.  u = fh + rh where fh / rh are the
  * top 32 bits of the 38-bit forward and reverse-complement codes (code >> 6): together they cover all 19 bases
  * and the sum is symmetric in the two strands (no canonical min in the hot loop); um = u * odd constant spreads
@@ -216,6 +237,8 @@ struct NtsmCountParams {
 	const uint2 *lut64;                /* fast path: per byte { code, (3 - code) | valid << 16 } */
 	const uint4 *blocks;               /* k = 19 fast path: minimizer-addressed 128-bit filter blocks */
 	NtsmBlockMap blk_map;              /* minimizer -> filter block offset */
+	const uint32_t *bloom;             /* two-level path: one-word Bloom over the distinct site minimizers (L2 resident) */
+	uint32_t bloom_words;
 	const uint32_t *prefilter;         /* fast path, drain only: plain 2-bit Bloom over canonical codes (L2 resident) */
 	uint32_t pf_shift;                 /* word index = h1(fold) >> pf_shift; bits = h2(fold) & 31, (h2 >> 5) & 31 */
 	uint32_t debug;                    /* ablation switches (NTSM_DEBUG_KERNEL): 1 = drain discards its queue, 2 = drain stops after the k-mer rebuild */

@@ -44,6 +44,8 @@ typedef int ntsm_i32x4 __attribute__((ext_vector_type(4)));
  * declared by name.  (descriptor, index, byte offset inside the element, scalar offset, cache policy) */
 __device__ ntsm_u32x4 ntsm_struct_buffer_load_b128(ntsm_i32x4 rsrc, int vindex, int voffset, int soffset, int aux)
 		__asm("llvm.amdgcn.struct.buffer.load.v4i32");
+__device__ uint32_t ntsm_struct_buffer_load_b32(ntsm_i32x4 rsrc, int vindex, int voffset, int soffset, int aux)
+		__asm("llvm.amdgcn.struct.buffer.load.i32");
 
 namespace {
 
@@ -257,6 +259,9 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(
 #ifndef NTSM_STEP_POS
 #define NTSM_STEP_POS 8                                /* positions between issuing the filter-block loads and testing them (8 or 4) */
 #endif
+#ifndef NTSM_TWO_STEP_POS
+#define NTSM_TWO_STEP_POS 4                            /* the same for the two-level form (one more load level in flight per step) */
+#endif
 constexpr int kFastC = NTSM_FAST_C;
 #ifdef NTSM_WITH_TAB
 constexpr int kListC = 128;                            /* list mode (tiles handed over by the tabulated kernel): always 32 KiB tiles */
@@ -276,13 +281,17 @@ __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
 
 /* KMODE 0: k = 19 with every constant folded (the reference default and all BASELINE configurations).
  * KMODE 2 .. 9: any other k of ntsm_fast_plan(), KMODE = number of minimizer candidates; k, the minimizer length and
- * the candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each). */
-template <int KMODE, bool PER_READ, int C>
+ * the candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each).
+ * TWO (k = 19, large site sets): 14-mer minimizers and a Bloom word over the distinct site minimizers in front of the
+ * block -- phase B between A and C: a run's block is only requested when its Bloom word passes (ntsm_device.h). */
+template <int KMODE, bool PER_READ, int C, bool TWO>
 __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_mz_kernel(const NtsmCountParams p)
 {
-	constexpr int VPT = C / 16, NB = C / 8, HB = NTSM_STEP_POS;
+	static_assert(!TWO || KMODE == 0, "two-level path: k = 19 only");
+	constexpr int VPT = C / 16, NB = C / 8, HB = TWO ? NTSM_TWO_STEP_POS : NTSM_STEP_POS;
 	constexpr bool GEN = KMODE != 0;
-	constexpr int W = KMODE == 0 ? NTSM_FAST_W : KMODE;
+	constexpr int MM = TWO ? NTSM_TWO_M : NTSM_FAST_M;                     /* minimizer length of the k = 19 kernels */
+	constexpr int W = KMODE == 0 ? NTSM_FAST_K - MM + 1 : KMODE;
 	static_assert(W >= 2 && W <= 9, "sliding minimum: 2 .. 9 candidates");
 	const uint32_t gk = GEN ? p.fk_k : (uint32_t) NTSM_FAST_K;            /* wave-uniform run-time k of the general kernels */
 	const uint32_t g_a2 = p.fk_a2, g_mmask = (1u << p.fk_m2) - 1u, g_rsh = 64u - p.fk_m2 - p.fk_a2, g_fsh = 64u - 2u * gk;
@@ -303,6 +312,11 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 	const unsigned long long blk_base = (unsigned long long) p.blocks;
 	const ntsm_i32x4 blk_rsrc = { (int) (uint32_t) blk_base, (int) ((uint32_t) (blk_base >> 32) | (16u << 16)),
 			(int) (p.blk_bytes >> 4), 0x00020000 };
+	/* two-level path: the Bloom words, 4-byte stride, same addressing */
+	const unsigned long long blm_base = (unsigned long long) p.bloom;
+	const ntsm_i32x4 blm_rsrc = { (int) (uint32_t) blm_base, (int) ((uint32_t) (blm_base >> 32) | (4u << 16)),
+			(int) p.bloom_words, 0x00020000 };
+	const uint32_t bloom_words = p.bloom_words;
 	uint32_t nk_s = 0, nh = 0;                           /* nk_s: wave-uniform (scalar) count of valid windows */
 
 #ifdef NTSM_WITH_TAB
@@ -371,10 +385,13 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		}
 		/* order hash of the newest candidate m-mer: the one ending `a` bases behind the newest base */
 		auto mmer_g = [&]() -> uint32_t {
-			if (!GEN) return ntsm_mmer_hash(min(F & NTSM_MMER_MASK, R >> (32 - 2 * NTSM_FAST_M)));
+			if (!GEN) {
+				const uint32_t cm = min(F & ((1u << (2 * MM)) - 1u), R >> (32 - 2 * MM));
+				return MM <= 12 ? ntsm_mmer_hash(cm) : ntsm_mmer_hash_wide(cm);
+			}
 			const uint32_t fm = __builtin_amdgcn_alignbit(Fh, F, g_a2) & g_mmask;
 			const uint32_t rm = (uint32_t) (((((unsigned long long) R) << 32) | Ro) >> g_rsh) & g_mmask;
-			return ntsm_mmer_hash(min(fm, rm));
+			return ntsm_mmer_hash_m(min(fm, rm), p.fk_m2 >> 1);
 		};
 		/* forward word of the window's first 16 bases (k < 16: its code, left-aligned) */
 		auto f_top = [&]() -> uint32_t { return (uint32_t) ((((((unsigned long long) Fh) << 32) | F) << g_fsh) >> 32); };
@@ -525,7 +542,8 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		 *         offset -- the buffer load returns 0 for it and makes no memory request
 		 *   sel   ld | bad: the lane replaces its cached block by what came back, which for a bad lane is 0: an
 		 *         invalid window then fails the bit test by itself and needs no mask of its own */
-		struct BlockState { uint32_t u[HB], f3[HB], r[HB]; unsigned long long sel[HB]; uint4 bl[HB]; };   /* one step: HB positions */
+		struct BlockState { uint32_t u[HB], f3[HB], r[HB]; unsigned long long sel[HB]; uint4 bl[HB];
+			uint32_t h[TWO ? HB : 1], bw[TWO ? HB : 1]; unsigned long long ld[TWO ? HB : 1]; };   /* one step: HB positions */
 		auto lut_reads = [&](const uint2 v, const int j0, uint2 (&e)[HB]) {   /* the table reads of one step issue together */
 			const uint32_t w[2] = { v.x, v.y };
 #pragma unroll
@@ -559,7 +577,8 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				const unsigned long long bad = __builtin_amdgcn_ballot_w64(run <= gk);
 				const unsigned long long ld = ~bad & (__builtin_amdgcn_ballot_w64(mz != mz_prev) | bad_prev);
 				B.sel[jj] = ld | bad;
-				const uint32_t bi = ntsm_block_idx(mz, blk_map);
+				const uint32_t bh = ntsm_block_hash(mz);
+				const uint32_t bi = TWO ? ntsm_range(bh, bloom_words) : ntsm_range(bh, blk_map.n_blocks);   /* TWO: the Bloom word first */
 #ifdef NTSM_ABLATION
 				/* 8: no lane requests a block (all out of range); 16: every lane requests block 0 (one request per load) */
 				/* 32 / 64: only 9/16 (5/16) of the runs request their block -- what an on-chip minimizer-set test would leave */
@@ -571,11 +590,31 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				mz_prev = mz;
 				bad_prev = bad;
 				nk_s += (uint32_t) __popcll(~bad);
-				{   /* issue each block load as soon as its offset is known: earlier positions get the rest of the block as
+				if (TWO) {
+					B.bw[jj] = ntsm_struct_buffer_load_b32(blm_rsrc, (int) idx, 0, 0, 0);
+					B.h[jj] = bh;
+					B.ld[jj] = ld;
+				} else {   /* issue each block load as soon as its offset is known: earlier positions get the rest of the block as
 				     * cover (+2 % over issuing the eight loads together at the end of the phase) */
 					const ntsm_u32x4 bv = ntsm_struct_buffer_load_b128(blk_rsrc, (int) idx, 0, 0, 0);
 					B.bl[jj] = make_uint4(bv.x, bv.y, bv.z, bv.w);
 				}
+			}
+		};
+		/* Phase B (two-level path): test the run-start lanes' Bloom words (two bits, byte-aligned fields of the block
+		 * hash, sign-bit test like phase C) and request the 128-bit block only for the runs that pass.  Every other lane
+		 * -- no run start, or Bloom says "not a site minimizer" -- sends an out-of-range index and gets 0 back; a
+		 * run-start lane that failed thereby caches an all-zero block, and its windows fail phase C by themselves. */
+		auto phase_b = [&](BlockState &B) {
+#pragma unroll
+			for (int j = 0; j < HB; ++j) {
+				uint32_t s0, s1;
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(s0) : "v"(B.h[j]), "v"(B.bw[j]));
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(s1) : "v"(B.h[j]), "v"(B.bw[j]));
+				const unsigned long long go = B.ld[j] & __builtin_amdgcn_ballot_w64((int32_t) (s0 & s1) < 0);
+				const uint32_t idx = __builtin_amdgcn_inverse_ballot_w64(go) ? ntsm_range(B.h[j], blk_map.n_blocks) : 0xFFFFFFFFu;
+				const ntsm_u32x4 bv = ntsm_struct_buffer_load_b128(blk_rsrc, (int) idx, 0, 0, 0);
+				B.bl[j] = make_uint4(bv.x, bv.y, bv.z, bv.w);
 			}
 		};
 		auto block_end = [&](const uint32_t (&gg)[8], const uint32_t (&fh)[8], const uint32_t (&m2)[8]) {
@@ -635,6 +674,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 			for (int j0 = 0; j0 < 8; j0 += HB) {
 				lut_reads(v, j0, e);
 				phase_a(e, S, j0, gg, fh, pm, m2);
+				if (TWO) phase_b(S);
 				phase_c(S, t * C + b * 8 + j0);
 			}
 			block_end(gg, fh, m2);
@@ -804,6 +844,8 @@ void build_lut(uint8_t *lut)
 	lut['T'] = lut['t'] = lut['U'] = lut['u'] = 3;
 }
 
+bool ntsm_wants_two_level(uint64_t n_keys) { return (12ull * n_keys + 127) / 128 > (9ull << 15); }   /* 12 bits per key > 4.5 MiB */
+
 uint64_t mask_for_k(int k) { return k >= 32 ? 0ull : ((1ull << (2 * k)) - 1); }   /* k = 32: see header */
 
 uint64_t inv_odd(uint64_t a)                 /* multiplicative inverse mod 2^64 */
@@ -839,6 +881,13 @@ struct ntsm_ctx {
 	uint64_t n_slots = 0;
 	uint4 *d_blocks = nullptr;                 /* k = 19 fast path: minimizer-addressed 128-bit filter blocks */
 	uint64_t n_blocks = 0;                     /* number of 128-bit filter blocks: mult * 2^e, mult in {1, 3} */
+	uint32_t *d_bloom = nullptr;               /* two-level path: Bloom over the distinct site minimizers, in front of the blocks */
+	uint32_t n_bloom_words = 0;
+	bool two_level = false;                    /* k = 19 and the blocked filter would not fit the L2: 14-mer minimizers + d_bloom */
+	uint32_t n_site_minimizers = 0;            /* distinct minimizers of the site k-mers (two-level path only) */
+	uint32_t bloom_words_req = 0;              /* tuning: Bloom size in words (0 = automatic) */
+	bool prefilter_forced = false;             /* tuning (code 2): keep the drain's Bloom on the two-level path as well */
+	int filter_log2_req = 0;                   /* tuning: what ntsm_set_tuning asked for (kept across rebuilds) */
 	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
 	uint32_t prefilter_log2 = 0;               /* log2(bits) */
 	NtsmBlockMap blk_map = { 1 };
@@ -972,7 +1021,13 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			filter[bit >> 5] |= 1u << (bit & 31);
 		}
 	};
-	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k);
+	/* Two-level path (k = 19): chosen when the blocked filter at 12 bits per key is far enough out of the L2 (more than
+	 * 4.5 MiB: beyond ~3.1 M site k-mers.  Measured one level / two levels: 1.9 M keys 797 / 665, 2.6 M 715 / 650, 4.0 M
+	 * 457 / 623, 8.0 M 292 / 530, 16 M 219 / 404 Gbases/s), or forced either way with ntsm_set_kernel (4 / 2). */
+	c->two_level = c->k == NTSM_FAST_K && c->kernel_variant != 1 &&
+		(c->kernel_variant == 4 || (c->kernel_variant == 0 && filter_log2_req == 0 && ntsm_wants_two_level(n)));
+	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k, c->two_level);
+	std::vector<uint32_t> bloom;
 	auto build_blocks = [&]() {
 		/* minimizer-addressed blocked filter (k = 19 and the other k of ntsm_fast_plan).  Size = smallest of {2^e,
 		 * 3 * 2^(e-2)} blocks with at least 12 bits per key: 3 MiB for the 1.54 M-key human set -- it must leave room in the
@@ -984,15 +1039,19 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			} else if (filter_log2_req >= 10 && filter_log2_req <= 30) {
 				e = (uint32_t) filter_log2_req - 7;
 			} else {
-				const uint64_t want = (12ull * n + 127) / 128;                /* blocks */
-				while ((1ull << e) < want && e < 21) ++e;
+				/* blocks: 12 bits per key; 16 on the two-level path, where the filter lives in the Infinity Cache anyway and a
+				 * false positive costs a bucket read from HBM (16 M keys: 32 MiB measured 400 Gbases/s against 391 at 24 MiB) */
+				const uint64_t want = ((c->two_level ? 16ull : 12ull) * n + 127) / 128;
+				while ((1ull << e) < want && e < 23) ++e;
 				if (e > 8 && (3ull << (e - 2)) >= want) { mult = 3; e -= 2; }   /* 0.75 * 2^e is enough */
 			}
-			if (e > 20) e = 20;
+			if (e > 22) e = 22;
 			if (e < 4) e = 4;
 			c->n_blocks = (uint64_t) mult << e;
 			c->blk_map.n_blocks = (uint32_t) c->n_blocks;
 			blocks.assign(c->n_blocks * 4, 0u);
+			std::vector<uint32_t> site_mz;                            /* two-level path: every site k-mer's minimizer */
+			if (c->two_level) site_mz.resize(n);
 			for (uint32_t i = 0; i < n; ++i) {
 				const uint64_t x = c->canon[i];
 				/* reverse complement of the 2k-bit code: complement, then reverse the 2-bit groups of the 64-bit word */
@@ -1005,14 +1064,32 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 				for (uint32_t j = plan.a; j < plan.a + plan.w; ++j) {     /* the candidate m-mer at offset j from the end, and its reverse complement */
 					const uint32_t sub = (uint32_t) (x >> (2 * j)) & mmask;
 					const uint32_t rsub = (uint32_t) (rc >> (2 * (plan.k - plan.m - j))) & mmask;
-					mz = std::min(mz, ntsm_mmer_hash(std::min(sub, rsub)));
+					mz = std::min(mz, ntsm_mmer_hash_m(std::min(sub, rsub), plan.m));
 				}
+				if (c->two_level) site_mz[i] = mz;
 				const uint32_t u = ntsm_kmer_sum(ntsm_code_top(x, plan.k), ntsm_code_top(rc, plan.k)), um = ntsm_kmer_mix(u);
 				uint32_t *blk = &blocks[(size_t) ntsm_block_idx(mz, c->blk_map) * 4];
 				blk[0] |= 1u << NTSM_KBIT0(u);
 				blk[1] |= 1u << NTSM_KBIT1(um);
 				blk[2] |= 1u << NTSM_KBIT2(um);
 				blk[3] |= 1u << NTSM_KBIT3(um);
+			}
+			if (c->two_level) {
+				/* Bloom over the DISTINCT site minimizers: one 32-bit word per minimizer, two bits; 12 bits per distinct
+				 * minimizer, at most 2.25 MiB: it has to stay in the 4 MiB L2 beside the lines the block and bucket reads
+				 * pull through it (16 M keys, 1.75 / 2 / 2.25 / 2.5 / 3 MiB: 376 / 391 / 394 / 393 / 379 Gbases/s); any
+				 * word count will do, the index is a multiply-high range reduction */
+				std::sort(site_mz.begin(), site_mz.end());
+				site_mz.erase(std::unique(site_mz.begin(), site_mz.end()), site_mz.end());
+				c->n_site_minimizers = (uint32_t) site_mz.size();
+				const uint64_t want_w = std::max<uint64_t>(1024, std::min<uint64_t>(2304ull * 256, (12ull * site_mz.size() + 31) / 32));
+				const uint32_t nw = c->bloom_words_req ? c->bloom_words_req : (uint32_t) ((want_w + 31) & ~31ull);
+				c->n_bloom_words = nw;
+				bloom.assign(nw, 0u);
+				for (uint32_t mz : site_mz) {
+					const uint32_t h = ntsm_block_hash(mz);
+					bloom[ntsm_range(h, nw)] |= (1u << NTSM_BLOOM_BIT0(h)) | (1u << NTSM_BLOOM_BIT1(h));
+				}
 			}
 #ifdef NTSM_ABLATION                                              /* tools/ablate*.py builds only: wrong counts */
 			if (getenv("NTSM_DEBUG_ZERO_FILTER")) std::fill(blocks.begin(), blocks.end(), 0u);
@@ -1024,16 +1101,21 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		 * (1 MiB for the human set: with the 3 MiB first level it still fits the 4 MiB per-XCD L2) */
 		if (plan.mode >= 0) {
 			uint32_t pl = 10;
-			while (pl < 28 && (1ull << pl) < 5ull * n) ++pl;
+			/* The drain's Bloom pays while it sits in the L2 beside the first level (1 MiB for the human set).  A set that takes
+			 * the two-level path is too big for that: its Bloom (16 MiB at 16 M keys) would be one more Infinity-Cache
+			 * request per positive in front of the bucket read it is meant to save -- so it is left out (4 KiB, every bit
+			 * set: always an L2 hit, always passes). */
+			const bool pass_all = c->two_level && !c->prefilter_forced;
+			while (!pass_all && pl < 28 && (1ull << pl) < 5ull * n) ++pl;
 #ifdef NTSM_ABLATION
 			if (const char *ev = getenv("NTSM_PREFILTER_LOG2")) pl = (uint32_t) atoi(ev);
 #endif
 			if (pl < 10) pl = 10;
 			if (pl > 30) pl = 30;
 			c->prefilter_log2 = pl;
-			prefilter.assign((1ull << pl) / 32, 0u);
+			prefilter.assign((1ull << pl) / 32, pass_all ? 0xFFFFFFFFu : 0u);
 			const uint32_t pshift = 32 - (pl - 5);
-			for (uint32_t i = 0; i < n; ++i) {
+			for (uint32_t i = 0; i < n && !pass_all; ++i) {
 				const uint32_t f = ntsm_fold(c->canon[i]), g1 = ntsm_h1(f), g2 = ntsm_h2(f);
 				prefilter[g1 >> pshift] |= (1u << (g2 & 31u)) | (1u << ((g2 >> 5) & 31u));
 			}
@@ -1091,8 +1173,15 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	/* upload */
 	if (c->d_blocks) (void) hipFree(c->d_blocks);
 	if (c->d_prefilter) (void) hipFree(c->d_prefilter);
+	if (c->d_bloom) (void) hipFree(c->d_bloom);
 	c->d_blocks = nullptr;
 	c->d_prefilter = nullptr;
+	c->d_bloom = nullptr;
+	if (!c->two_level) c->n_bloom_words = 0;
+	if (!bloom.empty()) {
+		HIPCHK(hipMalloc(&c->d_bloom, bloom.size() * sizeof(uint32_t)));
+		HIPCHK(hipMemcpy(c->d_bloom, bloom.data(), bloom.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
 	if (!prefilter.empty()) {
 		HIPCHK(hipMalloc(&c->d_prefilter, prefilter.size() * sizeof(uint32_t)));
 		HIPCHK(hipMemcpy(c->d_prefilter, prefilter.data(), prefilter.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1211,8 +1300,10 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 #endif
 	p.pf_shift = 32 - (c->prefilter_log2 - 5);
 	p.blk_bytes = (uint32_t) (c->n_blocks * 16);
-	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k);
+	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k, c->two_level);
 	const bool fast = plan.mode >= 0 && c->d_blocks && c->kernel_variant != 1;
+	p.bloom = c->d_bloom;
+	p.bloom_words = c->n_bloom_words;
 	p.fk_k = plan.k; p.fk_m2 = 2 * plan.m; p.fk_a2 = 2 * plan.a;
 #ifdef NTSM_WITH_TAB
 	const bool tab = fast && !per_read && c->tab_ok && c->d_tblocks && c->kernel_variant == 3;
@@ -1343,15 +1434,19 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		/* whatever follows on the launch stream (the list walker, the timing event, the caller's sync) sees the look-ups done */
 		HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[(tab_segs - 1) & 1], 0));
 		if (tab_segs > 1) HIPCHK(hipStreamWaitEvent(st, tab_sb.ev_look[tab_segs & 1], 0));
-		hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kListC>), dim3((unsigned) std::min<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles)), dim3(kThreads), 0, st, p);
+		hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kListC, false>), dim3((unsigned) std::min<uint64_t>((uint64_t) c->n_cu * 4, p.n_tiles)), dim3(kThreads), 0, st, p);
 		c->n_launch[0]++;
 	} else
 #endif
 	if (fast) {
 		const dim3 g((unsigned) grid), b(kThreads);
 #define NTSM_MZ_CASE(M_) \
-		case 2 * M_: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, false, kFastC>), g, b, 0, st, p); break; \
-		case 2 * M_ + 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, true, kFastC>), g, b, 0, st, p); break;
+		case 2 * M_: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, false, kFastC, false>), g, b, 0, st, p); break; \
+		case 2 * M_ + 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, true, kFastC, false>), g, b, 0, st, p); break;
+		if (c->two_level) {
+			if (per_read) hipLaunchKernelGGL((ntsm_count_mz_kernel<0, true, kFastC, true>), g, b, 0, st, p);
+			else hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kFastC, true>), g, b, 0, st, p);
+		} else
 		switch (plan.mode * 2 + (per_read ? 1 : 0)) {
 		NTSM_MZ_CASE(0) NTSM_MZ_CASE(2) NTSM_MZ_CASE(3) NTSM_MZ_CASE(4) NTSM_MZ_CASE(5) NTSM_MZ_CASE(6) NTSM_MZ_CASE(7) NTSM_MZ_CASE(8) NTSM_MZ_CASE(9)
 		default: return NTSM_ERR_STATE;
@@ -1673,7 +1768,7 @@ void ntsm_destroy(ntsm_ctx *c)
 	if (c->d_tab) (void) hipFree(c->d_tab);
 	if (c->d_tblocks) (void) hipFree(c->d_tblocks);
 #endif
-	void *ptrs[] = { c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
+	void *ptrs[] = { c->d_bloom, c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
 	for (void *p : ptrs) if (p) (void) hipFree(p);
 	delete c;
 }
@@ -2050,7 +2145,32 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
 	c->grid_blocks = grid_blocks;
+	if (filter_log2_bits == 2 || filter_log2_bits == 3) {       /* 2 / 3: two-level path with / without the drain's Bloom (default: without) */
+		c->prefilter_forced = filter_log2_bits == 2;
+		filter_log2_bits = 1000000 + (int) (c->bloom_words_req / 256u);     /* falls into the rebuild below (0 words = automatic) */
+	}
+	if ((filter_log2_bits >= 200 && filter_log2_bits < 300) || filter_log2_bits >= 1000000) {
+		/* 200 + v: two-level path, Bloom of 2^v bits; 250 + v: 3 * 2^v bits; 1000000 + w: w KiB */
+		if (filter_log2_bits >= 1000000) {
+			c->bloom_words_req = (uint32_t) (filter_log2_bits - 1000000) * 256u;
+			if (c->bloom_words_req > (1u << 26)) return NTSM_ERR_ARG;
+		} else {
+			const int v = filter_log2_bits >= 250 ? filter_log2_bits - 250 : filter_log2_bits - 200;
+			if (v < 10 || v > 28) return NTSM_ERR_ARG;
+			c->bloom_words_req = (filter_log2_bits >= 250 ? 3u : 1u) << (v - 5);
+		}
+		filter_log2_bits = c->filter_log2_req;
+		HIPCHK(hipSetDevice(c->device));
+		rc = build_tables(c, filter_log2_bits);
+		if (rc) return rc;
+		HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
+		HIPCHK(hipDeviceSynchronize());
+		c->total_bases = c->reads_consumed = 0;
+		c->early_stop = c->reduced = false;
+		return NTSM_OK;
+	}
 	if (filter_log2_bits > 0) {
+		c->filter_log2_req = filter_log2_bits;
 		rc = build_tables(c, filter_log2_bits);              /* rebuilds filters and table: counts start from zero again */
 		if (rc) return rc;
 		HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
@@ -2074,13 +2194,27 @@ int ntsm_rccl_probe(void) { return rccl_bind().ok ? NTSM_OK : NTSM_ERR_RCCL; }
 
 int ntsm_set_kernel(ntsm_ctx *c, int variant)
 {
-	if (!c || variant < 0 || variant > 3) return NTSM_ERR_ARG;
+	if (!c || variant < 0 || variant > 4) return NTSM_ERR_ARG;
 #ifndef NTSM_WITH_TAB
 	if (variant == 3) return NTSM_ERR_ARG;                 /* the tabulated kernel is not part of this build (make tab) */
 #endif
+	if (variant == 4 && c->k != NTSM_FAST_K) return NTSM_ERR_ARG;
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
+	const int before = c->kernel_variant;
 	c->kernel_variant = variant;
+	/* one-level and two-level filters are different tables (12-mer / 14-mer minimizers): a change of level rebuilds them */
+	const bool want_two = c->k == NTSM_FAST_K && variant != 1 && variant != 3 &&
+		(variant == 4 || (variant == 0 && c->filter_log2_req == 0 && ntsm_wants_two_level(c->n_kmers)));
+	if (variant != 1 && variant != 3 && want_two != c->two_level) {
+		HIPCHK(hipSetDevice(c->device));
+		rc = build_tables(c, c->filter_log2_req);
+		if (rc) { c->kernel_variant = before; return rc; }
+		HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
+		HIPCHK(hipDeviceSynchronize());
+		c->total_bases = c->reads_consumed = 0;
+		c->early_stop = c->reduced = false;
+	}
 	return NTSM_OK;
 }
 
@@ -2105,7 +2239,9 @@ int ntsm_debug_stats(ntsm_ctx *c, uint64_t out[8])
 	uint64_t dv[4] = { 0, 0, 0, 0 };
 	HIPCHK(hipMemcpy(dv, c->d_totals, sizeof dv, hipMemcpyDeviceToHost));
 	out[4] = dv[2];
-	out[5] = out[6] = out[7] = 0;
+	out[5] = c->two_level ? 1 : 0;
+	out[6] = c->n_bloom_words;
+	out[7] = c->n_site_minimizers;
 	return NTSM_OK;
 }
 

@@ -140,12 +140,17 @@ def test_random_reads_vs_oracle_n10(nt, n10):
     fp = OracleFP(path)
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)   # one long "read": terminators reset windows
     _, _, ocnt = fp.kmers()
-    # kernel variants (0 = minimizer-blocked fast path, 1 = generic) and filter sizes must all agree
-    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (0, 124)):
+    # kernel variants (0 = minimizer-blocked fast path, 1 = generic, 4 = its two-level form with 14-mer minimizers and a
+    # minimizer Bloom, which a set of this size would not take by itself) and filter / Bloom sizes must all agree
+    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (0, 124), (4, 0), (4, 214), (4, 266), (4, 22)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         if flog:
             ctx.set_tuning(flog, 0)
+        st = ctx.debug_stats()
+        assert st["two_level"] == (variant == 4) and (st["bloom_words"] > 0) == (variant == 4), st
+        if (variant, flog) == (4, 214):
+            assert st["bloom_words"] == (1 << 14) // 32 and 300_000 < st["site_minimizers"] < len(sites.keys)
         half = (n // 2) * s.stride
         ctx.submit(bases[:half], ends[:n // 2])                            # two batches -> both staging slots
         ctx.submit(bases[half:], ends[n // 2:] - np.uint64(half))
@@ -314,8 +319,11 @@ def test_early_stop_resident_and_batched(nt, n10):
         assert fp.max_hits == thr
         fp.process_flat(bases, ends)
         assert fp.early_term
-        for n_batches in (1, 7):
+        for n_batches in (1, 7, -7):                        # -7: the two-level form of the kernel (and of its per-read variant)
             ctx = nt.Context(sites.keys, max_hits=thr)
+            if n_batches < 0:
+                ctx.set_kernel(4)
+                n_batches = -n_batches
             per = -(-n // n_batches)
             for b in range(n_batches):
                 lo, hi = b * per, min(n, (b + 1) * per)
@@ -424,11 +432,17 @@ def test_large_site_set_regime(nt, tmp_path):
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)
     want = fp.kmers()[2]
     assert fp.total_hits > 100_000
-    for variant, flog in ((0, 0), (1, 0), (0, 123)):
+    for variant, flog in ((0, 0), (1, 0), (0, 123), (2, 0), (0, 272)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         if flog:
             ctx.set_tuning(flog, 0)
+        # a set of this size takes the two-level form by itself (2.25 MiB Bloom over ~6.5 M distinct 14-mer minimizers in front
+        # of the 32 MiB blocked filter); 2 forces the one-level form, an explicit block-filter size keeps it as well
+        st = ctx.debug_stats()
+        assert st["two_level"] == ((variant, flog) in ((0, 0), (0, 272), (1, 0))), (variant, flog, st)   # 1: tables as created, generic kernel
+        if (variant, flog) == (0, 0):
+            assert st["bloom_words"] == 2304 * 256 and 5_000_000 < st["site_minimizers"] < 8_000_000, st
         ctx.submit(bases, ends)
         t = ctx.sync()
         assert np.array_equal(ctx.counts(), want), (variant, flog)
@@ -958,7 +972,7 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
         fp.L.ntsm_oracle_fp_insert_count(fp.h, buf.tobytes(), n)
         ends = np.array([n], dtype=np.uint64)
         flat = np.concatenate([buf, np.frombuffer(b"N", dtype=np.uint8)])
-        for variant in (0, 1):
+        for variant in (0, 1) + ((4,) if k == 19 else ()):     # 4: the two-level form of the k = 19 kernel
             ctx = nt.Context(sites.keys, k=k)
             ctx.set_kernel(variant)
             ctx.submit(flat, ends)
@@ -967,6 +981,10 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
             assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, n), (k, variant)
             ctx.close()
         assert fp.total_hits > 100
+    ctx = nt.Context(sites.keys, k=32)
+    with pytest.raises(nt.NtsmError):                        # the two-level form exists for k = 19 only
+        ctx.set_kernel(4)
+    ctx.close()
 
 
 def test_tabulated_kernel_paths(nt, n10, tmp_path):
