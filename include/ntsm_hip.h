@@ -104,6 +104,20 @@ int ntsm_lane_acquire(ntsm_lane *lane, uint8_t **bases, uint64_t *cap_bytes, uin
 		uint64_t *cap_reads);
 int ntsm_lane_submit(ntsm_lane *lane, uint64_t n_bytes, uint32_t n_reads);
 int ntsm_lane_close(ntsm_lane *lane);
+/* Packed batches on a lane: what crosses PCIe is 2 bits of code + 1 validity bit per stream position -- the five classes
+ * the reference's byte table knows (vendor/KseqHashIterator.hpp:114-127: A a 0x00 | C c 0x01 | G g 0x02 | T t U u 0x03 |
+ * everything else) -- 3/8 byte per position instead of 1; the library unpacks it on the device into the flat stream
+ * (codes as raw bytes 0..3, invalid positions as 'N') and counts that.  Layout of a batch of P positions:
+ *     codes[P / 4]   position p -> bits 2(p & 3).. of codes[p >> 2]  (little endian inside the byte; 0 where invalid)
+ *     valid[P / 8]   position p -> bit p & 7 of valid[p >> 3]
+ * Reads need not be separated by exactly one invalid position: any number >= 1 will do (a window restarts at every
+ * invalid position, KseqHashIterator.hpp:106); ntsm_amd/csrc/host/pack2.hpp starts every read at a multiple of 8.
+ * acquire hands out the two planes inside the lane's pinned slot (room for *cap_positions, a multiple of 32; buffers may
+ * be written up to that position whatever the batch ends up holding); submit takes n_positions (a multiple of 8), the
+ * number of reads and the sum of their lengths (the reference's m_totalBases, which the packed form no longer shows).
+ * Both kinds of batches may be mixed on one lane. */
+int ntsm_lane_acquire_packed(ntsm_lane *lane, uint8_t **codes, uint8_t **valid, uint64_t *cap_positions);
+int ntsm_lane_submit_packed(ntsm_lane *lane, uint64_t n_positions, uint32_t n_reads, uint64_t n_bases);
 
 /* Initialise the HIP runtime and the device context of `device` and put `n_streams` ready-made streams into the
  * library's per-device stream pool (a context takes 3, plus 2 once it has lanes; streams go back to the pool when

@@ -63,6 +63,8 @@ _sig(H, "ntsm_lane_open", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTE
 _sig(H, "ntsm_lane_acquire", C.c_int, [C.c_void_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p])
 _sig(H, "ntsm_lane_submit", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32])
 _sig(H, "ntsm_lane_close", C.c_int, [C.c_void_p])
+_sig(H, "ntsm_lane_acquire_packed", C.c_int, [C.c_void_p, C.POINTER(u8p), C.POINTER(u8p), u64p])
+_sig(H, "ntsm_lane_submit_packed", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64])
 _sig(H, "ntsm_warmup", C.c_int, [C.c_int, C.c_int])
 _sig(H, "ntsm_staging_pool", C.c_int, [C.c_uint64])
 _sig(H, "ntsm_count_resident", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int])
@@ -99,6 +101,8 @@ _sig(HO, "ntsm_host_flatten", C.c_int, [C.c_char_p, C.POINTER(u8p), u64p, C.POIN
 _sig(HO, "ntsm_host_free", None, [C.c_void_p])
 _sig(HO, "ntsm_host_gunzip", C.c_int, [C.c_char_p, C.c_int, C.c_uint, C.POINTER(u8p), u64p])
 _sig(HO, "ntsm_host_flatten_parallel", C.c_int, [C.c_char_p, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, u64p])
+_sig(HO, "ntsm_host_pack2_append", C.c_uint64, [u8p, u8p, C.c_uint64, u8p, C.c_uint64, C.c_int])
+_sig(HO, "ntsm_host_pack2_impl", C.c_char_p, [])
 _sig(HO, "ntsm_host_format_counts", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)])
 _sig(HO, "ntsm_host_format_summary", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), u64p])
@@ -342,6 +346,20 @@ class Lane:
         C.memmove(hb, bases.ctypes.data, bases.size)
         C.memmove(hr, read_end.ctypes.data, read_end.size * 8)
         _chk(H.ntsm_lane_submit(self._h, bases.size, read_end.size), "ntsm_lane_submit")
+
+    def submit_packed(self, reads, force_scalar=False):
+        """acquire_packed + pack every read (bytes objects) with the host packer + submit_packed"""
+        pc, pv, cap = u8p(), u8p(), C.c_uint64()
+        _chk(H.ntsm_lane_acquire_packed(self._h, C.byref(pc), C.byref(pv), C.byref(cap)), "ntsm_lane_acquire_packed")
+        pos, n_bases = 0, 0
+        for r in reads:
+            if pos + (len(r) & ~31) + 32 > cap.value:                                   # pack2_extent
+                _chk(H.ntsm_lane_submit_packed(self._h, 0, 0, 0), "ntsm_lane_submit_packed")   # give the slot back
+                raise NtsmError("batch larger than the lane's slot")
+            buf = (C.c_uint8 * max(1, len(r))).from_buffer_copy(bytes(r) if len(r) else b"\0")
+            pos = HO.ntsm_host_pack2_append(pc, pv, pos, buf, len(r), int(force_scalar))
+            n_bases += len(r)
+        _chk(H.ntsm_lane_submit_packed(self._h, pos, len(reads), n_bases), "ntsm_lane_submit_packed")
 
     def close(self):
         if self._h:

@@ -11,6 +11,7 @@
 #include <thread>
 
 #include "gz_stream.hpp"
+#include "pack2.hpp"
 #include "parallel_fastq.hpp"
 #include <chrono>
 #include "report.hpp"
@@ -54,6 +55,7 @@ Feeder::Feeder(const Options &opt, ntsm_ctx *ctx, uint64_t max_hits, bool lane) 
 	if (m_useLane) {
 		/* N producers share the GPU: smaller slots keep the pinned footprint (and its allocation time) flat */
 		m_cfgBytes = std::max<uint64_t>(4096, std::min<uint64_t>(m_cfgBytes, lane_bytes(m_opt.threads)));
+		m_packed = m_opt.pack;
 		openLane();
 	} else {
 		int rc = ntsm_set_batch_capacity(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16);
@@ -81,6 +83,15 @@ void Feeder::finish()
 
 void Feeder::flush()
 {
+	if (m_packed) {
+		if (!m_codes || m_nReads == 0) return;
+		int rc = ntsm_lane_submit_packed(m_lane, m_pos, m_nReads, m_nBases);
+		if (rc) die(rc, "submit failed");
+		m_codes = m_valid = nullptr;
+		m_pos = m_nBases = 0;
+		m_nReads = 0;
+		return;
+	}
 	if (!m_bases || m_nReads == 0) return;
 	int rc = m_useLane ? ntsm_lane_submit(m_lane, m_fill, m_nReads) : ntsm_submit_staged(m_ctx, m_fill, m_nReads);
 	if (rc) die(rc, "submit failed");
@@ -121,8 +132,35 @@ void Feeder::feedFile(const std::string &fn, uint64_t offset)
 	}
 }
 
+/* one read into a packed lane: the same slot logic as below, in positions */
+void Feeder::feedPacked(const char *seq, uint64_t len)
+{
+	if (m_codes && packedExtent(len) > m_capPos) flush();
+	if (m_codes && m_nReads == 0 && packedExtent(len) > m_capPos) {   /* held but empty (after discard()) and too small: hand it back */
+		int rc = ntsm_lane_submit_packed(m_lane, 0, 0, 0);
+		if (rc) die(rc, "cannot return an empty staging slot");
+		m_codes = m_valid = nullptr;
+	}
+	if (!m_codes) {
+		if (len + 64 > (m_cfgBytes & ~31ull)) {                          /* a read longer than a slot: grow both slots */
+			m_cfgBytes = (len + 64) + (len + 64) / 2;
+			int rc = ntsm_lane_close(m_lane);
+			m_lane = nullptr;
+			if (rc) die(rc, "cannot grow staging buffers");
+			openLane();
+		}
+		int rc = ntsm_lane_acquire_packed(m_lane, &m_codes, &m_valid, &m_capPos);
+		if (rc) die(rc, "cannot acquire staging");
+		m_pos = m_nBases = 0;
+	}
+	m_pos = pack2_append(m_codes, m_valid, m_pos, seq, len);
+	m_nBases += len;
+	++m_nReads;
+}
+
 void Feeder::feedRead(const char *seq, uint64_t len)
 {
+	if (m_packed) { feedPacked(seq, len); return; }
 	if (m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)) flush();
 	if (m_earlyTerm) return;
 	if (m_bases && m_nReads == 0 && len + 1 > m_capBytes) {

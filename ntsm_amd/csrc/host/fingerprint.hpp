@@ -33,6 +33,9 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	/* Block size of the block-parallel FASTQ ingest (-t N, plain files).  A block's sequences (< half its bytes) fit
 	 * one 16 MiB lane slot, so a thread never has to wait for its predecessor in the middle of a block. */
 	uint64_t block_bytes = 16ull << 20;
+	/* Producer lanes send 2-bit codes + a validity bit per position (3/8 byte instead of 1 over PCIe; pack2.hpp) and the
+	 * device unpacks them.  NTSM_NO_PACK=1 sends the raw bytes instead (same counts: A/B of the two ingest forms). */
+	bool pack = true;
 };
 
 /* The staging batch one host thread is filling for a GPU context: the context's own slots (single-threaded and
@@ -49,11 +52,15 @@ public:
 	void feedRead(const char *seq, uint64_t len);
 	void flush();
 	/* Sink interface of the block-parallel ingest (parallel_fastq.hpp) */
-	bool has_room(uint64_t len) const { return !(m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads)); }
+	bool has_room(uint64_t len) const
+	{
+		if (m_packed) return !(m_codes && packedExtent(len) > m_capPos);
+		return !(m_bases && (m_fill + len + 1 > m_capBytes || m_nReads >= m_capReads));
+	}
 	void feed(const char *seq, uint64_t len) { feedRead(seq, len); }
 	/* Drop what is staged.  The slot stays acquired (it is handed back by the next submit), so feedRead() must still
 	 * be able to grow it: it checks the capacity whenever the batch is empty, not only when no slot is held. */
-	void discard() { m_fill = 0; m_nReads = 0; }
+	void discard() { m_fill = 0; m_nReads = 0; m_pos = 0; m_nBases = 0; }
 	void begin_block(size_t) { }
 	/* flush + close the lane (its totals fold into the context); the Feeder must not be fed afterwards */
 	void finish();
@@ -72,6 +79,13 @@ private:
 	uint64_t m_capBytes = 0, m_capReads = 0, m_fill = 0, m_cfgBytes = 0;
 	uint32_t m_nReads = 0;
 	bool m_earlyTerm = false;
+	/* packed lane (Options::pack): the two planes of the slot, its capacity in positions, the position the next read
+	 * starts at and the sum of the read lengths staged so far */
+	bool m_packed = false;
+	uint8_t *m_codes = nullptr, *m_valid = nullptr;
+	uint64_t m_capPos = 0, m_pos = 0, m_nBases = 0;
+	uint64_t packedExtent(uint64_t len) const { return m_pos + (len & ~31ull) + 32; }   /* pack2_extent */
+	void feedPacked(const char *seq, uint64_t len);
 };
 
 class FingerPrint {

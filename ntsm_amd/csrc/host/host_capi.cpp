@@ -9,6 +9,7 @@
 #include <zlib.h>
 
 #include "gz_stream.hpp"
+#include "pack2.hpp"
 #include "parallel_fastq.hpp"
 #include "report.hpp"
 #include "seq_reader.hpp"
@@ -76,6 +77,15 @@ int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint
 }
 
 void ntsm_host_free(void *p) { free(p); }
+
+uint64_t ntsm_host_pack2_append(uint8_t *codes, uint8_t *valid, uint64_t pos, const uint8_t *seq, uint64_t len, int force_scalar)
+{
+	ntsm::pack2_force_scalar(force_scalar != 0);
+	const uint64_t r = ntsm::pack2_append(codes, valid, pos, (const char *) seq, len);
+	ntsm::pack2_force_scalar(false);
+	return r;
+}
+const char *ntsm_host_pack2_impl(void) { return ntsm::pack2_impl(); }
 
 int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out, uint64_t *len)
 {

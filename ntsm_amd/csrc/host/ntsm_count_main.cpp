@@ -143,6 +143,7 @@ int main(int argc, char *argv[])
 		exit(EXIT_FAILURE);
 	}
 	if (const char *bb = getenv("NTSM_BATCH_BYTES")) opt.batch_bytes = strtoull(bb, nullptr, 10);   /* staging slot size */
+	if (getenv("NTSM_NO_PACK")) opt.pack = false;                                                  /* lanes send raw bytes instead of 2-bit codes + validity */
 	if (const char *pb = getenv("NTSM_BLOCK_BYTES")) opt.block_bytes = strtoull(pb, nullptr, 10);   /* block-parallel ingest block size */
 	const auto t0 = std::chrono::steady_clock::now();
 	const bool phases = opt.phase_times = getenv("NTSM_PHASE_TIMES") != nullptr;

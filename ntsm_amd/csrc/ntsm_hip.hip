@@ -704,6 +704,30 @@ __global__ void ntsm_gather_kernel(const uint64_t *table, const uint32_t *slot_o
 		dense[i] = *ntsm_count_ptr(table, (long long) slot_of[i]);
 }
 
+/* Packed producer lanes (ntsm_lane_acquire_packed): 2-bit codes + 1 validity bit per stream position come over PCIe
+ * (3/8 byte per position instead of 1); this kernel writes them out as the flat byte stream the count kernels read --
+ * a code as the raw byte 0..3, which the reference's table accepts as such (vendor/KseqHashIterator.hpp:115), an invalid
+ * position as 'N'.  One thread = 16 positions = one 16-byte store.  HBM-bound and tiny next to the link it relieves. */
+__global__ void ntsm_unpack_kernel(const uint32_t *codes, const uint16_t *valid, uint4 *out, unsigned long long n16)
+{
+	for (unsigned long long i = blockIdx.x * (unsigned long long) blockDim.x + threadIdx.x; i < n16; i += (unsigned long long) gridDim.x * blockDim.x) {
+		const uint32_t c = codes[i], v = valid[i];
+		uint32_t w[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			uint32_t x = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const int pos = 4 * q + b;
+				const uint32_t byte = ((v >> pos) & 1u) ? ((c >> (2 * pos)) & 3u) : 0x4Eu;
+				x |= byte << (8 * b);
+			}
+			w[q] = x;
+		}
+		out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+	}
+}
+
 __global__ void ntsm_zero_counts_kernel(uint64_t *table, unsigned long long n_buckets)
 {
 	for (unsigned long long b = blockIdx.x * (unsigned long long) blockDim.x + threadIdx.x; b < n_buckets; b += (unsigned long long) gridDim.x * blockDim.x) {
@@ -825,6 +849,7 @@ void stream_put(int device, hipStream_t s)    /* s must be idle (synchronised) *
 
 struct Slot {
 	uint8_t *h_bases = nullptr, *d_bases = nullptr;
+	uint8_t *d_packed = nullptr;               /* packed lanes: device copy of codes + validity bits (3/8 byte per position) */
 	uint64_t *h_read_end = nullptr, *d_read_end = nullptr;
 	uint64_t h_bases_bytes = 0, h_ends_bytes = 0;
 	bool ends_on_device = true;                /* false (lanes): read_end never leaves the host, plain malloc */
@@ -1256,8 +1281,9 @@ void free_slot(Slot &s)
 		else if (!pool_free(s.h_read_end, s.h_ends_bytes)) (void) hipHostFree(s.h_read_end);
 	}
 	if (s.d_bases) (void) hipFree(s.d_bases);
+	if (s.d_packed) (void) hipFree(s.d_packed);
 	if (s.d_read_end) (void) hipFree(s.d_read_end);
-	s.h_bases = s.d_bases = nullptr;
+	s.h_bases = s.d_bases = s.d_packed = nullptr;
 	s.h_read_end = s.d_read_end = nullptr;
 }
 
@@ -1944,6 +1970,55 @@ int ntsm_lane_submit(ntsm_lane *l, uint64_t n_bytes, uint32_t n_reads)
 	HIPCHK(hipEventRecord(s.done, s.stream));
 	s.busy = true;
 	l->total_bases += n_bytes - n_reads;
+	l->reads_consumed += n_reads;
+	l->next_slot ^= 1;
+	return NTSM_OK;
+}
+
+int ntsm_lane_acquire_packed(ntsm_lane *l, uint8_t **codes, uint8_t **valid, uint64_t *cap_positions)
+{
+	if (!l || !codes || !valid || !cap_positions) return NTSM_ERR_ARG;
+	HIPCHK(hipSetDevice(l->c->device));
+	Slot &s = l->slot[l->next_slot];
+	int rc = wait_slot(s);
+	if (rc) return rc;
+	/* the slot's pinned buffer (cap_bytes + 64) holds both planes of up to cap_bytes positions: 3/8 of it */
+	const uint64_t cap_pos = l->cap_bytes & ~31ull;
+	if (!s.d_packed) HIPCHK(hipMalloc(&s.d_packed, cap_pos / 4 + cap_pos / 8 + 64));
+	s.acquired = true;
+	*codes = s.h_bases;
+	*valid = s.h_bases + cap_pos / 4;
+	*cap_positions = cap_pos;
+	return NTSM_OK;
+}
+
+int ntsm_lane_submit_packed(ntsm_lane *l, uint64_t n_positions, uint32_t n_reads, uint64_t n_bases)
+{
+	if (!l) return NTSM_ERR_ARG;
+	Slot &s = l->slot[l->next_slot];
+	if (!s.acquired || !s.d_packed) return NTSM_ERR_STATE;
+	s.acquired = false;
+	const uint64_t cap_pos = l->cap_bytes & ~31ull;
+	if ((n_positions & 7) || n_positions > cap_pos || n_bases + n_reads > n_positions) return NTSM_ERR_ARG;
+	if (n_reads == 0 || n_positions == 0) return NTSM_OK;
+	ntsm_ctx *c = l->c;
+	HIPCHK(hipSetDevice(c->device));
+	/* whole groups of 32 positions cross the link and are unpacked: what lies between the end of the batch and the next
+	 * multiple of 32 is marked invalid here (the caller may have left anything there) */
+	const uint64_t n_out = (n_positions + 31) & ~31ull;
+	uint8_t *h_valid = s.h_bases + cap_pos / 4;
+	for (uint64_t p = n_positions; p < n_out; p += 8) h_valid[p >> 3] = 0;
+	HIPCHK(hipMemcpyAsync(s.d_packed, s.h_bases, n_out / 4, hipMemcpyHostToDevice, s.stream));
+	HIPCHK(hipMemcpyAsync(s.d_packed + cap_pos / 4, h_valid, n_out / 8, hipMemcpyHostToDevice, s.stream));
+	const uint64_t n16 = n_out / 16;
+	hipLaunchKernelGGL(ntsm_unpack_kernel, dim3((unsigned) std::min<uint64_t>(4096, (n16 + 255) / 256)), dim3(256), 0, s.stream,
+			(const uint32_t *) s.d_packed, (const uint16_t *) (s.d_packed + cap_pos / 4), (uint4 *) s.d_bases, (unsigned long long) n16);
+	HIPCHK(hipGetLastError());
+	int rc = launch_count(c, s.stream, s.d_bases, 0, n_out, nullptr, 0, false, +1);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(s.done, s.stream));
+	s.busy = true;
+	l->total_bases += n_bases;
 	l->reads_consumed += n_reads;
 	l->next_slot ^= 1;
 	return NTSM_OK;

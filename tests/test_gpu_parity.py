@@ -819,10 +819,11 @@ def test_cli_threads_over_files(nt, tmp_path):
     base = subprocess.run([exe, "-s", "sites200.fa"] + files, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert base.returncode == 0
     for t in ("2", "5", "16", "4 -g 0,0"):
-        p = subprocess.run([exe, "-s", "sites200.fa", "-t"] + t.split() + files, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        assert p.returncode == 0, p.stderr[-400:]
-        assert p.stdout == base.stdout
-        assert _summary(p.stderr) == _summary(base.stderr)
+        for env in (os.environ, dict(os.environ, NTSM_NO_PACK="1")):     # lanes send packed codes (default) or raw bytes
+            p = subprocess.run([exe, "-s", "sites200.fa", "-t"] + t.split() + files, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert p.returncode == 0, p.stderr[-400:]
+            assert p.stdout == base.stdout
+            assert _summary(p.stderr) == _summary(base.stderr)
     c = next(x for x in CASES if x["name"] == "m_file_boundary_continue")
     p = subprocess.run([exe] + c["args"] + ["-t", "8"] + c["files"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0 and p.stdout == open(os.path.join(G, "expected", c["stdout"]), "rb").read()
@@ -872,6 +873,56 @@ def test_producer_lanes_share_one_context(nt, tmp_path):
     with pytest.raises(nt.NtsmError):
         armed.open_lane()                                    # -m is defined on one ordered stream
     armed.close()
+
+
+def test_packed_lane_batches_vs_oracle(nt, tmp_path):
+    """ntsm_lane_acquire_packed / ntsm_lane_submit_packed: 2-bit codes + a validity bit per position cross PCIe and are
+    unpacked on the device.  Reads of every length 0..200 made of arbitrary bytes (all 256 values, raw codes 0..3,
+    lowercase, U, N runs), packed by the host packer (AVX2 and portable), mixed with byte batches on the same lane:
+    counts, k-mer / hit / base / read totals equal the oracle's on the same reads."""
+    rng = np.random.default_rng(11)
+    k = 19
+    letters = np.frombuffer(b"ACGTacgtUu\x00\x01\x02\x03", dtype=np.uint8)
+    reads = []
+    for i in range(6000):
+        L = int(rng.integers(0, 201)) if i % 7 else int(rng.integers(1000, 5000))
+        r = letters[rng.integers(0, len(letters), L)].copy()
+        junk = rng.random(L) < 0.02
+        r[junk] = rng.integers(0, 256, int(junk.sum()), dtype=np.uint8)
+        if i % 11 == 0 and L > 40:
+            r[10:10 + int(rng.integers(1, 25))] = ord("N")
+        reads.append(bytes(r))
+    path = str(tmp_path / "pk.fa")
+    with open(path, "wb") as f:                              # sites cut out of the reads: frequent hits
+        n_rec = 0
+        for r in reads:
+            if len(r) >= 60 and n_rec < 600:
+                seg = r[5:5 + int(rng.integers(k, 50))].replace(b">", b"A").replace(b"\n", b"C").replace(b"\r", b"G").replace(b"@", b"T").replace(b"+", b"A")
+                f.write(b">s%d\n" % (n_rec // 2) + seg + b"\n")
+                n_rec += 1
+    sites = nt.Sites(path, k=k, allow_dupes=True)
+    fp = OracleFP(path, k=k, dupes=True)
+    for r in reads:
+        fp.process(r)
+    assert fp.total_hits > 1000
+    for force_scalar in (False, True):
+        ctx = nt.Context(sites.keys, k=k)
+        lane = ctx.open_lane(1 << 20)
+        flat_reads, chunk = [], 500
+        for b in range(0, len(reads), chunk):
+            part = reads[b:b + chunk]
+            if (b // chunk) % 3 == 2:                        # every third batch as plain bytes on the same lane
+                bases, ends = nt.capi.flatten_reads(part)
+                lane.submit(bases, ends)
+            else:
+                lane.submit_packed(part, force_scalar=force_scalar)
+        with pytest.raises(nt.NtsmError):
+            lane.submit_packed([b"A" * (2 << 20)])           # larger than the slot
+        lane.close()
+        t = ctx.sync()
+        assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (fp.total_kmers, fp.total_hits, fp.total_bases, len(reads))
+        assert np.array_equal(ctx.counts(), fp.kmers()[2])
+        ctx.close()
 
 
 def test_staging_pool_and_stream_reuse(nt, tmp_path):

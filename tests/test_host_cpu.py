@@ -612,3 +612,62 @@ def test_minimizer_plan_is_strand_symmetric_for_every_k(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tools", "plan_check.cpp")], check=True)
     p = subprocess.run([exe], stdout=subprocess.PIPE)
     assert p.returncode == 0 and b"plans: 19, problems: 0" in p.stdout, p.stdout.decode()
+
+
+def test_pack2_packer_matches_the_byte_table(nt):
+    """Host packer of the packed producer lanes (ntsm_amd/csrc/host/pack2.hpp): 2-bit code + validity bit per position must
+    be exactly the class the reference's byte table gives the byte (vendor/KseqHashIterator.hpp:114-127: A a 0x00 | C c
+    0x01 | G g 0x02 | T t U u 0x03 | invalid), for every byte value, read lengths 0..200, both implementations; every
+    read starts at a multiple of 8 and is followed by 1..8 invalid positions; nothing before the batch start is touched."""
+    import ctypes as C
+    from ntsm_amd.capi import HO, u8p
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import lib
+    L = lib()
+    table = np.array([L.ntsm_oracle_nt4(b) for b in range(256)], dtype=np.uint8)     # the oracle's copy of the reference table
+    assert sorted(np.flatnonzero(table < 4).tolist()) == sorted([0, 1, 2, 3] + list(b"ACGTUacgtu"))
+    rng = np.random.default_rng(3)
+    assert HO.ntsm_host_pack2_impl() in (b"avx2", b"scalar")
+    for force in (0, 1):
+        for trial in range(120):
+            reads = []
+            for _ in range(int(rng.integers(1, 7))):
+                n = int(rng.integers(0, 201))
+                mode = int(rng.integers(0, 3))
+                if mode == 0:
+                    r = rng.integers(0, 256, n, dtype=np.uint8)
+                elif mode == 1:
+                    r = np.frombuffer(b"ACGTacgtUuNn\x00\x01\x02\x03", np.uint8)[rng.integers(0, 16, n)]
+                else:
+                    r = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)]
+                reads.append(r.astype(np.uint8).copy())
+            if trial == 0:
+                reads = [np.arange(256, dtype=np.uint8)]                                # every byte value once
+            starts, pos = [], 0
+            for r in reads:
+                starts.append(pos)
+                pos = (pos + len(r) + 8) & ~7
+            cap = ((pos + 63) // 32) * 32 + 64
+            cls = np.full(cap, 4, np.uint8)
+            for st, r in zip(starts, reads):
+                cls[st:st + len(r)] = table[r]
+            want_valid = np.packbits((cls < 4).astype(np.uint8), bitorder="little")
+            c4 = np.where(cls < 4, cls, 0).astype(np.uint8).reshape(-1, 4)
+            want_codes = (c4[:, 0] | (c4[:, 1] << 2) | (c4[:, 2] << 4) | (c4[:, 3] << 6)).astype(np.uint8)
+            codes, valid = np.full(cap // 4, 0xAA, np.uint8), np.full(cap // 8, 0x55, np.uint8)
+            at = 0
+            for r in reads:
+                buf = r if len(r) else np.zeros(1, np.uint8)
+                at = HO.ntsm_host_pack2_append(codes.ctypes.data_as(u8p), valid.ctypes.data_as(u8p), at, buf.ctypes.data_as(u8p), len(r), force)
+            assert at == pos
+            assert np.array_equal(codes[:pos // 4], want_codes[:pos // 4]) and np.array_equal(valid[:pos // 8], want_valid[:pos // 8]), (force, trial)
+
+
+def test_pack2_packer_under_sanitizers(tmp_path):
+    """tools/pack_sanitize.cpp under ASan + UBSan: the packer never writes past pack2_extent() nor reads past the read."""
+    exe = str(tmp_path / "pack_sanitize")
+    host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", host, "-o", exe,
+                    os.path.join(ROOT, "tools", "pack_sanitize.cpp"), os.path.join(host, "pack2.cpp")], check=True)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"pack2 sanitize ok" in p.stdout, p.stderr.decode()[-2000:]
