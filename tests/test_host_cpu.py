@@ -291,7 +291,7 @@ def test_block_parallel_ingest_under_tsan(nt, tmp_path):
     exe = str(tmp_path / "parallel_tsan")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
     srcs = [os.path.join(ROOT, "tools", "parallel_tsan.cpp")] + [os.path.join(host, f) for f in
-            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "gz_stream.cpp", "crc32_fast.cpp")]
+            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "gz_stream.cpp", "crc32_fast.cpp", "pack2.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
     fq = str(tmp_path / "t.fq")
