@@ -1105,6 +1105,20 @@ def test_resident_stream_beyond_4gib(nt, n10):
     del d
 
 
+def test_cli_clean_exit_runs_the_destructors(nt):
+    """The CLI leaves with _exit once everything is printed (process teardown of a HIP program costs ~0.13 s);
+    NTSM_CLEAN_EXIT=1 takes the ordinary way out -- lanes, contexts, streams and the pinned pool are destroyed -- and must
+    give the same bytes and exit status, single-threaded, with lanes and with an armed (-m) run."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    inp = os.path.join(G, "inputs")
+    for args in (["-s", "sites200.fa", "reads2k.fq"], ["-s", "sites200.fa", "-t", "4", "reads2k.fq", "reads600.fq.gz"],
+                 ["-s", "sites200.fa", "-m", "1", "reads2k.fq"]):
+        a = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, NTSM_CLEAN_EXIT="1"))
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
+        assert a.stdout == b.stdout and len(a.stdout) > 1000 and _summary(a.stderr) == _summary(b.stderr)
+
+
 def test_cli_reads_from_pipes(nt):
     """`ntsmCount -s sites.fa <(zcat a.fq.gz) <(cat b.fq)`: inputs that are pipes (process substitution) give the bytes
     of the same run on the files, with -t 1 and -t 2."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/isa_budget.py [out_dir] -- instruction budget of ntsm_count_mz_kernel<0, false, 128>'s main loop from the compiler's ISA.
+"""tools/isa_budget.py [out_dir] -- instruction budget of ntsm_count_mz_kernel<0, false, 128, false>'s main loop from the compiler's ISA.
 
 Compiles ntsm_amd/csrc/ntsm_hip.hip to gfx950 assembly, takes the basic blocks of the 8-position loop body (the
 block with the eight filter-block loads and the blocks it falls through to up to the loop's back edge) and prints
@@ -8,7 +8,7 @@ main_loop.s (the loop body as compiled) and isa_budget.txt."""
 import collections, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN12_GLOBAL__N_120ntsm_count_mz_kernelILi0ELb0ELi128EEEv15NtsmCountParams"
+KERNEL = "_ZN12_GLOBAL__N_120ntsm_count_mz_kernelILi0ELb0ELi128ELb0EEEv15NtsmCountParams"   # <KMODE 0, PER_READ false, C 128, TWO false>
 
 
 def main():
@@ -48,7 +48,7 @@ def main():
                 "queue push" if any(x.startswith("ds_write_b64") for x in blocks[b]) else
                 "phase A + C" if b == main_blk else "phase C of one position" if any("sdwa" in x for x in blocks[b]) else "control")
         rows.append((b, len(blocks[b]), v, kind))
-    lines = ["main loop block %s of ntsm_count_mz_kernel<0, false, 128>: straight-line part of one 8-position step" % main_blk,
+    lines = ["main loop block %s of ntsm_count_mz_kernel<0, false, 128, false>: straight-line part of one 8-position step" % main_blk,
              "(phase A of 8 positions + phase C up to the first position with a positive; the queue push and the drain are",
              " in the blocks behind it and run for the ~54 % of positions where some lane passes the filter)", "",
              "%-8s %8s %12s" % ("unit", "per 8", "per position")]
