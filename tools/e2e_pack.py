@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/e2e_pack.py [reads] [t,t,...] -- build/ntsmCount on ONE plain FASTQ with the producer lanes sending packed codes
-(default) or raw bytes (NTSM_NO_PACK=1): wall time, parse+count phase, identical stdout."""
+(default) or raw bytes (NTSM_NO_PACK=1), with and without the block prefault (NTSM_NO_PREFAULT=1), interleaved on the same file:
+wall time, parse+count phase (best of three), identical stdout."""
 import hashlib, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,9 +15,10 @@ fq = os.path.join(tmp, "reads.fq")
 t0 = time.perf_counter(); s.write_fastq(fq, 0, n, threads=32); print("file: %.2f GB written in %.1f s" % (os.path.getsize(fq) / 1e9, time.perf_counter() - t0), flush=True)
 sha = None
 for t in ts:
-    for mode, extra in (("packed", {}), ("bytes", {"NTSM_NO_PACK": "1"})):
+    for mode, extra in (("packed", {}), ("bytes", {"NTSM_NO_PACK": "1"}), ("packed/nopf", {"NTSM_NO_PREFAULT": "1"}),
+                        ("bytes/nopf", {"NTSM_NO_PACK": "1", "NTSM_NO_PREFAULT": "1"})):
         best = None
-        for rep in range(2):
+        for rep in range(3):
             t0 = time.perf_counter()
             p = subprocess.run([os.path.join(ROOT, "build", "ntsmCount"), "-s", sp, "-t", str(t), fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                env=dict(os.environ, NTSM_PHASE_TIMES="1", **extra))
@@ -29,5 +31,5 @@ for t in ts:
             ps = float(pc[0].split("parse+count")[1].split("s")[0]) if pc else float("nan")
             if best is None or dt < best[0]:
                 best = (dt, ps)
-        print("-t %2d %-6s wall %.3f s = %6.2f Gbases/s   parse+count %.3f s = %6.2f Gbases/s" % (t, mode, best[0], n * 150 / best[0] / 1e9, best[1], n * 150 / best[1] / 1e9), flush=True)
+        print("-t %2d %-11s wall %.3f s = %6.2f Gbases/s   parse+count %.3f s = %6.2f Gbases/s" % (t, mode, best[0], n * 150 / best[0] / 1e9, best[1], n * 150 / best[1] / 1e9), flush=True)
 os.unlink(fq)
