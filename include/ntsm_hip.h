@@ -181,12 +181,12 @@ int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
  * is proportional to what is consumed before the stop; 0 = the default (256 MiB).  Any value gives the same result. */
 int ntsm_set_armed_chunk(ntsm_ctx *ctx, uint64_t chunk_bytes);
 /* Kernel choice.  All choices give identical results.
- *   0  automatic: 13 <= k <= 31 the minimizer-blocked kernel, other k the generic kernel; k = 19 with a site set whose
- *      blocked filter is well out of the L2 (more than ~3.1 M k-mers) takes the two-level form of the kernel: 14-mer
+ *   0  automatic: 13 <= k <= 31 the minimizer-blocked kernel, other k the generic kernel; 15 <= k <= 31 with a site set
+ *      whose blocked filter is well out of the L2 (more than ~3.1 M k-mers) takes the two-level form of the kernel: 14-mer
  *      minimizers and a Bloom word over the distinct site minimizers in front of the block
  *   1  always the generic kernel
  *   2  the minimizer-blocked kernel, one level, whatever the size of the set
- *   4  k = 19 only: the two-level form, whatever the size of the set
+ *   4  15 <= k <= 31 only: the two-level form, whatever the size of the set
  *   3  the tabulated k = 19 kernel, a measured negative result (7 % slower) that only exists in
  *      -DNTSM_WITH_TAB builds (`make tab`: ntsm_amd/libntsm_hip_tab.so); the default library answers NTSM_ERR_ARG.
  * One-level and two-level filters are different tables: a call that changes the level rebuilds them, and counts and

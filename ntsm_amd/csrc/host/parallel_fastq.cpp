@@ -6,7 +6,6 @@
 #include <unistd.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 
 namespace ntsm {
@@ -99,19 +98,6 @@ bool ParallelFastq::wait_start(size_t b, uint64_t first, uint64_t *prev_end)
 		m_cv.notify_all();
 	}
 	return false;
-}
-
-void ParallelFastq::prefault(uint64_t lo, uint64_t hi) const
-{
-#ifdef MADV_POPULATE_READ
-	static const bool off = getenv("NTSM_NO_PREFAULT") != nullptr;
-	if (off) return;
-	const uint64_t page = 4096;
-	const uint64_t a = lo & ~(page - 1), z = std::min(m_size, hi + (64u << 10));
-	if (z > a) (void) madvise(const_cast<char *>(m_data) + a, z - a, MADV_POPULATE_READ);    /* failure (old kernel): the faults happen one by one */
-#else
-	(void) lo; (void) hi;
-#endif
 }
 
 void ParallelFastq::release(size_t b) const

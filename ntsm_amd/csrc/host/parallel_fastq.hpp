@@ -103,9 +103,6 @@ private:
 	/* drop block b's page-table entries (the page cache keeps the data): spreads the teardown of a multi-GB
 	 * mapping over the worker threads instead of paying it single-threaded in munmap */
 	void release(size_t b) const;
-	/* map [lo, hi) (+ the start of the next block, where this block's last record ends) with one call instead of one
-	 * page fault per 4 KiB: with many threads the faults serialise on the address-space lock (NTSM_NO_PREFAULT=1: off) */
-	void prefault(uint64_t lo, uint64_t hi) const;
 
 	template <class Sink> uint64_t work(Sink &s, size_t b)
 	{
@@ -113,7 +110,6 @@ private:
 		bool started = false;
 		uint64_t prev_end = 0, n = 0;
 		if (m_failBlock.load(std::memory_order_relaxed) < b) return 0;   /* the parallel phase already stopped before this block */
-		prefault(lo, hi);
 		const uint64_t first = b == 0 ? 0 : find_start(lo, hi);
 		s.begin_block(b);
 		if (first == kNone) {

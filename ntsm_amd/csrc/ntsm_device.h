@@ -68,8 +68,15 @@ struct NtsmFastPlan { int mode; uint32_t k, m, w, a; };      /* mode: -1 no fast
 NTSM_DHD NtsmFastPlan ntsm_fast_plan(uint32_t k, bool two_level = false)
 {
 	NtsmFastPlan pl = { -1, k, 0u, 0u, 0u };
-	if (k == NTSM_FAST_K && two_level) { pl.mode = 0; pl.m = NTSM_TWO_M; pl.w = NTSM_TWO_W; }
-	else if (k == NTSM_FAST_K) { pl.mode = 0; pl.m = NTSM_FAST_M; pl.w = NTSM_FAST_W; }
+	if (two_level && k >= NTSM_TWO_M + 1u && k <= 31u) {
+		/* two-level form: the same rules with 14-mers -- all k - 13 candidates (2 .. 7) up to k = 20, the 8 / 9 innermost beyond */
+		pl.m = NTSM_TWO_M;
+		if (k <= NTSM_TWO_M + 6u) pl.w = k - (NTSM_TWO_M - 1u);
+		else { pl.w = (k & 1u) ? 8u : 9u; pl.a = (k - NTSM_TWO_M - (pl.w - 1u)) / 2u; }
+		pl.mode = k == NTSM_FAST_K ? 0 : (int) pl.w;
+		return pl;
+	}
+	if (k == NTSM_FAST_K) { pl.mode = 0; pl.m = NTSM_FAST_M; pl.w = NTSM_FAST_W; }
 	else if (k >= 19 && k <= 31) { pl.m = 12; pl.w = (k & 1u) ? 8u : 9u; pl.a = (k - 12u - (pl.w - 1u)) / 2u; pl.mode = (int) pl.w; }
 	else if (k >= 13 && k < 19) { pl.m = 12; pl.w = k - 11u; pl.mode = (int) pl.w; }
 	return pl;

@@ -282,12 +282,11 @@ __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
 /* KMODE 0: k = 19 with every constant folded (the reference default and all BASELINE configurations).
  * KMODE 2 .. 9: any other k of ntsm_fast_plan(), KMODE = number of minimizer candidates; k, the minimizer length and
  * the candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each).
- * TWO (k = 19, large site sets): 14-mer minimizers and a Bloom word over the distinct site minimizers in front of the
- * block -- phase B between A and C: a run's block is only requested when its Bloom word passes (ntsm_device.h). */
+ * TWO (large site sets, 15 <= k <= 31): 14-mer minimizers and a Bloom word over the distinct site minimizers in front of
+ * the block -- phase B between A and C: a run's block is only requested when its Bloom word passes (ntsm_device.h). */
 template <int KMODE, bool PER_READ, int C, bool TWO>
 __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_mz_kernel(const NtsmCountParams p)
 {
-	static_assert(!TWO || KMODE == 0, "two-level path: k = 19 only");
 	constexpr int VPT = C / 16, NB = C / 8, HB = TWO ? NTSM_TWO_STEP_POS : NTSM_STEP_POS;
 	constexpr bool GEN = KMODE != 0;
 	constexpr int MM = TWO ? NTSM_TWO_M : NTSM_FAST_M;                     /* minimizer length of the k = 19 kernels */
@@ -387,11 +386,11 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		auto mmer_g = [&]() -> uint32_t {
 			if (!GEN) {
 				const uint32_t cm = min(F & ((1u << (2 * MM)) - 1u), R >> (32 - 2 * MM));
-				return MM <= 12 ? ntsm_mmer_hash(cm) : ntsm_mmer_hash_wide(cm);
+				return TWO ? ntsm_mmer_hash_wide(cm) : ntsm_mmer_hash(cm);
 			}
 			const uint32_t fm = __builtin_amdgcn_alignbit(Fh, F, g_a2) & g_mmask;
 			const uint32_t rm = (uint32_t) (((((unsigned long long) R) << 32) | Ro) >> g_rsh) & g_mmask;
-			return ntsm_mmer_hash_m(min(fm, rm), p.fk_m2 >> 1);
+			return TWO ? ntsm_mmer_hash_wide(min(fm, rm)) : ntsm_mmer_hash(min(fm, rm));   /* 14-mers / 12-mers */
 		};
 		/* forward word of the window's first 16 bases (k < 16: its code, left-aligned) */
 		auto f_top = [&]() -> uint32_t { return (uint32_t) ((((((unsigned long long) Fh) << 32) | F) << g_fsh) >> 32); };
@@ -728,6 +727,24 @@ __global__ void ntsm_unpack_kernel(const uint32_t *codes, const uint16_t *valid,
 	}
 }
 
+/* key table image on the device: all buckets { empty, empty, 0, 0 }, then every key to its slot */
+__global__ void ntsm_table_init_kernel(uint64_t *table, unsigned long long n_buckets)
+{
+	uint4 *t = reinterpret_cast<uint4 *>(table);
+	for (unsigned long long b = blockIdx.x * (unsigned long long) blockDim.x + threadIdx.x; b < n_buckets; b += (unsigned long long) gridDim.x * blockDim.x) {
+		t[2 * b] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+		t[2 * b + 1] = make_uint4(0u, 0u, 0u, 0u);
+	}
+}
+
+__global__ void ntsm_table_scatter_kernel(uint64_t *table, const uint32_t *slot_of, const uint64_t *canon, uint32_t n)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const unsigned long long slot = slot_of[i];
+		table[4 * (slot >> 1) + (slot & 1)] = canon[i];
+	}
+}
+
 __global__ void ntsm_zero_counts_kernel(uint64_t *table, unsigned long long n_buckets)
 {
 	for (unsigned long long b = blockIdx.x * (unsigned long long) blockDim.x + threadIdx.x; b < n_buckets; b += (unsigned long long) gridDim.x * blockDim.x) {
@@ -1046,10 +1063,10 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			filter[bit >> 5] |= 1u << (bit & 31);
 		}
 	};
-	/* Two-level path (k = 19): chosen when the blocked filter at 12 bits per key is far enough out of the L2 (more than
+	/* Two-level path (15 <= k <= 31): chosen when the blocked filter at 12 bits per key is far enough out of the L2 (more than
 	 * 4.5 MiB: beyond ~3.1 M site k-mers.  Measured one level / two levels: 1.9 M keys 797 / 665, 2.6 M 715 / 650, 4.0 M
 	 * 457 / 623, 8.0 M 292 / 530, 16 M 219 / 404 Gbases/s), or forced either way with ntsm_set_kernel (4 / 2). */
-	c->two_level = c->k == NTSM_FAST_K && c->kernel_variant != 1 &&
+	c->two_level = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 1 &&
 		(c->kernel_variant == 4 || (c->kernel_variant == 0 && filter_log2_req == 0 && ntsm_wants_two_level(n)));
 	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k, c->two_level);
 	std::vector<uint32_t> bloom;
@@ -1237,12 +1254,27 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	HIPCHK(hipMalloc(&c->d_keys, 2 * c->n_slots * sizeof(uint64_t)));   /* { key0, key1, count0, count1 } per bucket */
 	HIPCHK(hipMalloc(&c->d_slot_of, (n ? n : 1) * sizeof(uint32_t)));
 	HIPCHK(hipMemcpy(c->d_filter, filter.data(), filter.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	{
-		std::vector<uint64_t> table(2 * c->n_slots, 0);
-		for (uint64_t b = 0; b < c->n_slots / 2; ++b) { table[4 * b] = keys[2 * b]; table[4 * b + 1] = keys[2 * b + 1]; }
-		HIPCHK(hipMemcpy(c->d_keys, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-	}
 	if (n) HIPCHK(hipMemcpy(c->d_slot_of, c->slot_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	{
+		/* The bucket image { key0, key1, count0, count1 } is laid out on the device: every bucket starts empty with zeroed
+		 * counters, then the n keys are scattered to their slots -- 12 bytes per key cross PCIe instead of 32 bytes per
+		 * bucket of a table that is 2/3 empty, and the host never builds the image (64 MiB for the human set, 512 MiB for
+		 * 16 M keys). */
+		hipLaunchKernelGGL(ntsm_table_init_kernel, dim3(2048), dim3(256), 0, 0, c->d_keys, (unsigned long long) (c->n_slots / 2));
+		HIPCHK(hipGetLastError());
+		if (n) {
+			uint64_t *d_canon = nullptr;
+			HIPCHK(hipMalloc(&d_canon, (uint64_t) n * sizeof(uint64_t)));
+			hipError_t e1 = hipMemcpy(d_canon, c->canon.data(), (uint64_t) n * sizeof(uint64_t), hipMemcpyHostToDevice);
+			if (e1 == hipSuccess) {
+				hipLaunchKernelGGL(ntsm_table_scatter_kernel, dim3(1024), dim3(256), 0, 0, c->d_keys, c->d_slot_of, d_canon, n);
+				e1 = hipGetLastError();
+			}
+			if (e1 == hipSuccess) e1 = hipDeviceSynchronize();
+			(void) hipFree(d_canon);
+			HIPCHK(e1);
+		}
+	}
 	HIPCHK(hipDeviceSynchronize());                      /* tables and zeroed counters visible before any stream uses them */
 	return NTSM_OK;
 }
@@ -1469,15 +1501,21 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 #define NTSM_MZ_CASE(M_) \
 		case 2 * M_: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, false, kFastC, false>), g, b, 0, st, p); break; \
 		case 2 * M_ + 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, true, kFastC, false>), g, b, 0, st, p); break;
+#define NTSM_MZ2_CASE(M_) \
+		case 2 * M_: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, false, kFastC, true>), g, b, 0, st, p); break; \
+		case 2 * M_ + 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, true, kFastC, true>), g, b, 0, st, p); break;
 		if (c->two_level) {
-			if (per_read) hipLaunchKernelGGL((ntsm_count_mz_kernel<0, true, kFastC, true>), g, b, 0, st, p);
-			else hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kFastC, true>), g, b, 0, st, p);
+			switch (plan.mode * 2 + (per_read ? 1 : 0)) {
+			NTSM_MZ2_CASE(0) NTSM_MZ2_CASE(2) NTSM_MZ2_CASE(3) NTSM_MZ2_CASE(4) NTSM_MZ2_CASE(5) NTSM_MZ2_CASE(6) NTSM_MZ2_CASE(7) NTSM_MZ2_CASE(8) NTSM_MZ2_CASE(9)
+			default: return NTSM_ERR_STATE;
+			}
 		} else
 		switch (plan.mode * 2 + (per_read ? 1 : 0)) {
 		NTSM_MZ_CASE(0) NTSM_MZ_CASE(2) NTSM_MZ_CASE(3) NTSM_MZ_CASE(4) NTSM_MZ_CASE(5) NTSM_MZ_CASE(6) NTSM_MZ_CASE(7) NTSM_MZ_CASE(8) NTSM_MZ_CASE(9)
 		default: return NTSM_ERR_STATE;
 		}
 #undef NTSM_MZ_CASE
+#undef NTSM_MZ2_CASE
 		c->n_launch[1]++;
 	}
 	else if (per_read) {
@@ -2273,13 +2311,13 @@ int ntsm_set_kernel(ntsm_ctx *c, int variant)
 #ifndef NTSM_WITH_TAB
 	if (variant == 3) return NTSM_ERR_ARG;                 /* the tabulated kernel is not part of this build (make tab) */
 #endif
-	if (variant == 4 && c->k != NTSM_FAST_K) return NTSM_ERR_ARG;
+	if (variant == 4 && ntsm_fast_plan((uint32_t) c->k, true).m != NTSM_TWO_M) return NTSM_ERR_ARG;   /* 15 <= k <= 31 */
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
 	const int before = c->kernel_variant;
 	c->kernel_variant = variant;
 	/* one-level and two-level filters are different tables (12-mer / 14-mer minimizers): a change of level rebuilds them */
-	const bool want_two = c->k == NTSM_FAST_K && variant != 1 && variant != 3 &&
+	const bool want_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && variant != 1 && variant != 3 &&
 		(variant == 4 || (variant == 0 && c->filter_log2_req == 0 && ntsm_wants_two_level(c->n_kmers)));
 	if (variant != 1 && variant != 3 && want_two != c->two_level) {
 		HIPCHK(hipSetDevice(c->device));

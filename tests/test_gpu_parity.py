@@ -279,13 +279,19 @@ def test_minimizer_fast_path_every_k(nt, tmp_path):
         bases, ends = nt.capi.flatten_reads(reads)
         fp.process_flat(bases, ends)
         want = fp.kmers()[2]
-        for variant in (0, 1):
+        for variant in (0, 1) + ((4,) if k >= 15 else ()):     # 4: the two-level form (14-mer minimizers + minimizer Bloom), 15 <= k <= 31
             ctx = nt.Context(sites.keys, k=k)
-            ctx.set_kernel(variant)
+            if variant == 4 or k >= 15:
+                ctx.set_kernel(variant)
+            else:
+                with pytest.raises(nt.NtsmError):
+                    ctx.set_kernel(4)                        # k = 13, 14 have no 14-mer minimizers
+                ctx.set_kernel(variant)
             ctx.submit(bases, ends)
             t = ctx.sync()
             st = ctx.debug_stats()
-            assert (st["launches_k19"] > 0) == (variant == 0) and (st["launches_generic"] > 0) == (variant == 1), (k, st)
+            assert (st["launches_k19"] > 0) == (variant != 1) and (st["launches_generic"] > 0) == (variant == 1), (k, st)
+            assert st["two_level"] == (variant == 4), (k, st)
             assert np.array_equal(ctx.counts(), want), (k, variant)
             assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases), (k, variant)
             ctx.close()
@@ -296,6 +302,8 @@ def test_minimizer_fast_path_every_k(nt, tmp_path):
         fm.process_flat(bases, ends)
         assert fm.early_term
         ctx = nt.Context(sites.keys, k=k, max_hits=thr)
+        if k >= 15 and k % 2 == 0:
+            ctx.set_kernel(4)                                # the per-read instantiation of the two-level form as well
         ctx.submit(bases, ends)
         t = ctx.sync()
         assert t.early_stop == 1 and t.reads_consumed == fm.reads_processed, k
@@ -1033,7 +1041,7 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
             ctx.close()
         assert fp.total_hits > 100
     ctx = nt.Context(sites.keys, k=32)
-    with pytest.raises(nt.NtsmError):                        # the two-level form exists for k = 19 only
+    with pytest.raises(nt.NtsmError):                        # the two-level form exists for 15 <= k <= 31
         ctx.set_kernel(4)
     ctx.close()
 

@@ -605,13 +605,14 @@ def test_reader_on_a_fifo(nt, tmp_path):
 
 def test_minimizer_plan_is_strand_symmetric_for_every_k(tmp_path):
     """tools/plan_check.cpp: the functions shared by the filter builder and the kernel (ntsm_device.h) for every k the
-    minimizer-blocked kernel takes (13..31): candidate offsets symmetric inside the k-mer, and minimizer, filter-bit hash and
-    block index equal for a k-mer and its reverse complement (the reference counts canonical k-mers, vendor/KseqHashIterator.hpp:87-93;
+    minimizer-blocked kernel takes (13..31, 12-mer minimizers) and for its two-level form (15..31, 14-mer minimizers + Bloom
+    word): candidate offsets symmetric inside the k-mer, and minimizer, filter-bit hash, block index, Bloom word and Bloom
+    bits equal for a k-mer and its reverse complement (the reference counts canonical k-mers, vendor/KseqHashIterator.hpp:87-93;
     a strand-dependent filter address would drop one strand of a site k-mer)."""
     exe = str(tmp_path / "plan_check")
     subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tools", "plan_check.cpp")], check=True)
     p = subprocess.run([exe], stdout=subprocess.PIPE)
-    assert p.returncode == 0 and b"plans: 19, problems: 0" in p.stdout, p.stdout.decode()
+    assert p.returncode == 0 and b"plans: 36, problems: 0" in p.stdout, p.stdout.decode()
 
 
 def test_pack2_packer_matches_the_byte_table(nt):

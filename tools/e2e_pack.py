@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/e2e_pack.py [reads] [t,t,...] -- build/ntsmCount on ONE plain FASTQ with the producer lanes sending packed codes
-(default) or raw bytes (NTSM_NO_PACK=1), with and without the block prefault (NTSM_NO_PREFAULT=1), interleaved on the same file:
-wall time, parse+count phase (best of three), identical stdout."""
+(default) or raw bytes (NTSM_NO_PACK=1), interleaved on the same file: wall time, parse+count phase (best of three),
+identical stdout."""
 import hashlib, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,8 +15,7 @@ fq = os.path.join(tmp, "reads.fq")
 t0 = time.perf_counter(); s.write_fastq(fq, 0, n, threads=32); print("file: %.2f GB written in %.1f s" % (os.path.getsize(fq) / 1e9, time.perf_counter() - t0), flush=True)
 sha = None
 for t in ts:
-    for mode, extra in (("packed", {}), ("bytes", {"NTSM_NO_PACK": "1"}), ("packed/nopf", {"NTSM_NO_PREFAULT": "1"}),
-                        ("bytes/nopf", {"NTSM_NO_PACK": "1", "NTSM_NO_PREFAULT": "1"})):
+    for mode, extra in (("packed", {}), ("bytes", {"NTSM_NO_PACK": "1"})):
         best = None
         for rep in range(3):
             t0 = time.perf_counter()
