@@ -262,9 +262,6 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(
 #ifndef NTSM_TWO_STEP_POS
 #define NTSM_TWO_STEP_POS 4                            /* the same for the two-level form (one more load level in flight per step) */
 #endif
-#ifndef NTSM_PAIR_DEFAULT
-#define NTSM_PAIR_DEFAULT 0                            /* 1: k = 19 takes the pair form of the kernel by itself (ntsm_set_kernel 5 forces it) */
-#endif
 constexpr int kFastC = NTSM_FAST_C;
 #ifdef NTSM_WITH_TAB
 constexpr int kListC = 128;                            /* list mode (tiles handed over by the tabulated kernel): always 32 KiB tiles */
@@ -287,17 +284,13 @@ __device__ __forceinline__ int ntsm_tile_addr(int row, int byte_in_row)
  * the candidate offset are run-time parameters, the rolling words are 64 bits wide (two registers each).
  * TWO (large site sets, 15 <= k <= 31): 14-mer minimizers and a Bloom word over the distinct site minimizers in front of
  * the block -- phase B between A and C: a run's block is only requested when its Bloom word passes (ntsm_device.h). */
-/* PAIR (k = 19, one level): neighbouring 19-mers share 18 bases, and a read k-mer that is a site k-mer shares its first or
- * its last 18 bases with each neighbour -- so the filter holds those 18-mers of every site k-mer and ONE test per two
- * positions (on the 18-mer the two k-mers have in common, 7 candidate 12-mers) covers both; a pass queues both k-mers. */
-template <int KMODE, bool PER_READ, int C, bool TWO, bool PAIR = false>
+template <int KMODE, bool PER_READ, int C, bool TWO>
 __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm_count_mz_kernel(const NtsmCountParams p)
 {
 	constexpr int VPT = C / 16, NB = C / 8, HB = TWO ? NTSM_TWO_STEP_POS : NTSM_STEP_POS;
-	static_assert(!PAIR || (KMODE == 0 && !TWO && !PER_READ && HB % 2 == 0), "pair form: k = 19, one level, plain batches");
 	constexpr bool GEN = KMODE != 0;
 	constexpr int MM = TWO ? NTSM_TWO_M : NTSM_FAST_M;                     /* minimizer length of the k = 19 kernels */
-	constexpr int W = PAIR ? NTSM_FAST_K - MM : KMODE == 0 ? NTSM_FAST_K - MM + 1 : KMODE;   /* PAIR: the 7 12-mers of the shared 18-mer */
+	constexpr int W = KMODE == 0 ? NTSM_FAST_K - MM + 1 : KMODE;
 	static_assert(W >= 2 && W <= 9, "sliding minimum: 2 .. 9 candidates");
 	const uint32_t gk = GEN ? p.fk_k : (uint32_t) NTSM_FAST_K;            /* wave-uniform run-time k of the general kernels */
 	const uint32_t g_a2 = p.fk_a2, g_mmask = (1u << p.fk_m2) - 1u, g_rsh = 64u - p.fk_m2 - p.fk_a2, g_fsh = 64u - 2u * gk;
@@ -424,10 +417,9 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #pragma unroll
 				for (int i = 1; i < 8; ++i) gprev[i] = gw[i];
 #pragma unroll
-				for (int i = 2; i < 8; ++i) m2prev[i] = PAIR ? (i >= 3 ? min(gw[i - 1], gw[i - 2]) : 0xFFFFFFFFu) : min(gw[i], gw[i - 1]);
+				for (int i = 2; i < 8; ++i) m2prev[i] = min(gw[i], gw[i - 1]);
 			}
 		}
-		uint32_t run_even = 1;                              /* PAIR: run counter after the even position of the current pair */
 		uint32_t mz_prev = 0;
 		uint4 cur = make_uint4(0, 0, 0, 0);                  /* the lane's cached 128-bit filter block */
 		unsigned long long bad_prev = ~0ull;                /* nothing cached at the start of a chunk */
@@ -550,8 +542,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		 *   sel   ld | bad: the lane replaces its cached block by what came back, which for a bad lane is 0: an
 		 *         invalid window then fails the bit test by itself and needs no mask of its own */
 		struct BlockState { uint32_t u[HB], f3[HB], r[HB]; unsigned long long sel[HB]; uint4 bl[HB];
-			uint32_t h[TWO ? HB : 1], bw[TWO ? HB : 1]; unsigned long long ld[TWO ? HB : 1];
-			unsigned long long badk[PAIR ? HB : 1]; };   /* one step: HB positions */
+			uint32_t h[TWO ? HB : 1], bw[TWO ? HB : 1]; unsigned long long ld[TWO ? HB : 1]; };   /* one step: HB positions */
 		auto lut_reads = [&](const uint2 v, const int j0, uint2 (&e)[HB]) {   /* the table reads of one step issue together */
 			const uint32_t w[2] = { v.x, v.y };
 #pragma unroll
@@ -566,34 +557,6 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				NTSM_STEP(e[jj])
 				fh[j] = F;
 				gg[j] = NTSM_MMER_G();
-				if (PAIR) {
-					/* every position: the k-mer's two words (for the queue) and its validity; odd positions: the 18-mer shared by
-					 * this k-mer and the one before -- bases [e - 18, e - 1] -- with its 7 candidate 12-mers ending at e - 7 .. e - 1
-					 * (minimum of three pair minima and one single), its validity (18 valid bases at e - 1) and its block */
-					auto G = [&](int q) { return q >= 0 ? gg[q] : gprev[q + 8]; };
-					auto M2 = [&](int q) { return q >= 0 ? m2[q] : m2prev[q + 8]; };
-					B.f3[jj] = j >= 3 ? fh[j - 3] : (j == 0 ? fc0 : (j == 1 ? fc1 : fc2));
-					B.r[jj] = R;
-					const unsigned long long badk = __builtin_amdgcn_ballot_w64(run <= (uint32_t) NTSM_FAST_K);
-					B.badk[jj] = badk;
-					nk_s += (uint32_t) __popcll(~badk);
-					if (j & 1) {
-						m2[j] = min(G(j - 1), G(j - 2));
-						const uint32_t mzp = min(min(m2[j], M2(j - 2)), min(M2(j - 4), G(j - 7)));
-						const unsigned long long badm = __builtin_amdgcn_ballot_w64(run_even <= (uint32_t) (NTSM_FAST_K - 1));
-						const unsigned long long ldp = ~badm & (__builtin_amdgcn_ballot_w64(mzp != mz_prev) | bad_prev);
-						B.sel[jj] = ldp | badm;
-						const uint32_t idxp = __builtin_amdgcn_inverse_ballot_w64(ldp) ? ntsm_range(ntsm_block_hash(mzp), blk_map.n_blocks) : 0xFFFFFFFFu;
-						const ntsm_u32x4 bvp = ntsm_struct_buffer_load_b128(blk_rsrc, (int) idxp, 0, 0, 0);
-						B.bl[jj] = make_uint4(bvp.x, bvp.y, bvp.z, bvp.w);
-						B.u[jj] = ntsm_kmer_sum(B.f3[jj], B.r[jj - 1]);      /* first 16 bases of the 18-mer, reverse word of its last 16 */
-						mz_prev = mzp;
-						bad_prev = badm;
-					} else {
-						run_even = run;
-					}
-					continue;
-				}
 				uint32_t mz;
 				if (W >= 8) {
 					pm = min(pm, gg[j]);
@@ -663,7 +626,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #pragma unroll
 				for (int j = 2; j < 8; ++j) gprev[j] = gg[j];
 #pragma unroll
-				for (int j = 4; j < 8; ++j) if (!PAIR || (j & 1)) m2prev[j] = m2[j];   /* PAIR: pair minima exist at odd positions only */
+				for (int j = 4; j < 8; ++j) m2prev[j] = m2[j];
 			}
 		};
 		/* Phase C: four-bit test against the (possibly just fetched) block.  word << field (NTSM_KBITn: bit 31 - field)
@@ -674,7 +637,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		 * this loop, 53.2 instead of 52.2 ms per 3e8 reads.) */
 		auto phase_c = [&](const BlockState &B, const int pos0) {
 #pragma unroll
-			for (int j = PAIR ? 1 : 0; j < HB; j += PAIR ? 2 : 1) {
+			for (int j = 0; j < HB; ++j) {
 				const bool sel = __builtin_amdgcn_inverse_ballot_w64(B.sel[j]);
 				cur.x = sel ? B.bl[j].x : cur.x;
 				cur.y = sel ? B.bl[j].y : cur.y;
@@ -688,25 +651,6 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(s3) : "v"(um), "v"(cur.w));
 				const bool pass = (int32_t) (__builtin_amdgcn_bitop3_b32(s0, s1, s2, 0x80) & s3) < 0;
 				const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-				if (PAIR) {
-					/* the shared 18-mer passed: both k-mers of the pair go to the queue, each if it is a valid window; one round
-					 * per k-mer so that a round adds at most 64 entries to at most 63 (the queue holds 128) */
-					if (m) {
-#pragma unroll
-						for (int q = 1; q >= 0; --q) {
-							const unsigned long long mq = m & ~B.badk[j - q];
-							if (mq) {
-								if (__builtin_amdgcn_inverse_ballot_w64(mq)) {
-									const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mq, 0u));
-									queue[at] = make_uint2(B.f3[j - q], B.r[j - q]);
-								}
-								qn += (uint32_t) __popcll(mq);
-								if (qn >= 64) drain(false);
-							}
-						}
-					}
-					continue;
-				}
 				if (m) {
 					if (pass) {
 						const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
@@ -982,7 +926,6 @@ struct ntsm_ctx {
 	uint32_t *d_bloom = nullptr;               /* two-level path: Bloom over the distinct site minimizers, in front of the blocks */
 	uint32_t n_bloom_words = 0;
 	bool two_level = false;                    /* k = 19 and the blocked filter would not fit the L2: 14-mer minimizers + d_bloom */
-	bool pair_mode = false;                    /* k = 19: the blocked filter holds the 18-mers shared by neighbouring k-mers; one test per two positions */
 	uint32_t n_site_minimizers = 0;            /* distinct minimizers of the site k-mers (two-level path only) */
 	uint32_t bloom_words_req = 0;              /* tuning: Bloom size in words (0 = automatic) */
 	bool prefilter_forced = false;             /* tuning (code 2): keep the drain's Bloom on the two-level path as well */
@@ -1048,19 +991,6 @@ struct ntsm_lane {
 };
 
 namespace {
-
-/* Which form of the minimizer-blocked kernel a context's tables are for (ntsm_set_kernel codes: 0 automatic, 1 generic kernel
- * -- tables as they are --, 2 one level / every position, 4 two levels, 5 one level / pairs of positions). */
-struct FilterMode { bool two_level, pair; };
-FilterMode filter_mode_for(const ntsm_ctx *c, int variant, int filter_log2_req)
-{
-	FilterMode m = { false, false };
-	if (variant == 1 || variant == 3) { m.two_level = c->two_level; m.pair = c->pair_mode; return m; }
-	const bool can_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M;
-	m.two_level = can_two && (variant == 4 || (variant == 0 && filter_log2_req == 0 && ntsm_wants_two_level(c->n_kmers)));
-	m.pair = !m.two_level && c->k == NTSM_FAST_K && (variant == 5 || (variant == 0 && NTSM_PAIR_DEFAULT));
-	return m;
-}
 
 int build_tables(ntsm_ctx *c, int filter_log2_req)
 {
@@ -1136,11 +1066,8 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	/* Two-level path (15 <= k <= 31): chosen when the blocked filter at 12 bits per key is far enough out of the L2 (more than
 	 * 4.5 MiB: beyond ~3.1 M site k-mers.  Measured one level / two levels: 1.9 M keys 797 / 665, 2.6 M 715 / 650, 4.0 M
 	 * 457 / 623, 8.0 M 292 / 530, 16 M 219 / 404 Gbases/s), or forced either way with ntsm_set_kernel (4 / 2). */
-	{
-		const FilterMode fm = filter_mode_for(c, c->kernel_variant == 1 || c->kernel_variant == 3 ? 0 : c->kernel_variant, filter_log2_req);
-		c->two_level = fm.two_level;
-		c->pair_mode = fm.pair;
-	}
+	c->two_level = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 1 &&
+		(c->kernel_variant == 4 || (c->kernel_variant == 0 && filter_log2_req == 0 && ntsm_wants_two_level(n)));
 	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k, c->two_level);
 	std::vector<uint32_t> bloom;
 	auto build_blocks = [&]() {
@@ -1167,43 +1094,27 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 			blocks.assign(c->n_blocks * 4, 0u);
 			std::vector<uint32_t> site_mz;                            /* two-level path: every site k-mer's minimizer */
 			if (c->two_level) site_mz.resize(n);
-			/* reverse complement of a 2L-bit code: complement, then reverse the 2-bit groups of the 64-bit word */
-			auto revcomp = [](uint64_t x, uint32_t len) {
+			for (uint32_t i = 0; i < n; ++i) {
+				const uint64_t x = c->canon[i];
+				/* reverse complement of the 2k-bit code: complement, then reverse the 2-bit groups of the 64-bit word */
 				uint64_t rc = ~x;
 				rc = ((rc >> 2) & 0x3333333333333333ull) | ((rc & 0x3333333333333333ull) << 2);
 				rc = ((rc >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((rc & 0x0F0F0F0F0F0F0F0Full) << 4);
-				return __builtin_bswap64(rc) >> (64 - 2 * len);
-			};
-			/* one filter entry: a sequence of `len` bases (either strand), minimizer candidates = the m-mers at offsets a .. a + w - 1 */
-			auto insert = [&](uint64_t x, uint32_t len, uint32_t m, uint32_t w, uint32_t a) {
-				const uint64_t rc = revcomp(x, len);
-				const uint32_t mmask = (1u << (2 * m)) - 1u;
+				rc = __builtin_bswap64(rc) >> (64 - 2 * plan.k);
+				const uint32_t mmask = (1u << (2 * plan.m)) - 1u;
 				uint32_t mz = 0xFFFFFFFFu;
-				for (uint32_t j = a; j < a + w; ++j) {                   /* the candidate m-mer at offset j from the end, and its reverse complement */
+				for (uint32_t j = plan.a; j < plan.a + plan.w; ++j) {     /* the candidate m-mer at offset j from the end, and its reverse complement */
 					const uint32_t sub = (uint32_t) (x >> (2 * j)) & mmask;
-					const uint32_t rsub = (uint32_t) (rc >> (2 * (len - m - j))) & mmask;
-					mz = std::min(mz, ntsm_mmer_hash_m(std::min(sub, rsub), m));
+					const uint32_t rsub = (uint32_t) (rc >> (2 * (plan.k - plan.m - j))) & mmask;
+					mz = std::min(mz, ntsm_mmer_hash_m(std::min(sub, rsub), plan.m));
 				}
-				const uint32_t u = ntsm_kmer_sum(ntsm_code_top(x, len), ntsm_code_top(rc, len)), um = ntsm_kmer_mix(u);
+				if (c->two_level) site_mz[i] = mz;
+				const uint32_t u = ntsm_kmer_sum(ntsm_code_top(x, plan.k), ntsm_code_top(rc, plan.k)), um = ntsm_kmer_mix(u);
 				uint32_t *blk = &blocks[(size_t) ntsm_block_idx(mz, c->blk_map) * 4];
 				blk[0] |= 1u << NTSM_KBIT0(u);
 				blk[1] |= 1u << NTSM_KBIT1(um);
 				blk[2] |= 1u << NTSM_KBIT2(um);
 				blk[3] |= 1u << NTSM_KBIT3(um);
-				return mz;
-			};
-			for (uint32_t i = 0; i < n; ++i) {
-				const uint64_t x = c->canon[i];
-				if (c->pair_mode) {
-					/* pair mode: what is tested is the 18-mer two neighbouring 19-mers share, so the filter holds the first 18
-					 * and the last 18 bases of every site k-mer (a read k-mer that is a site k-mer has one of them in common with
-					 * each of its neighbours); 7 candidate 12-mers */
-					insert(x >> 2, NTSM_FAST_K - 1, NTSM_FAST_M, NTSM_FAST_K - NTSM_FAST_M, 0);
-					insert(x & ((1ull << (2 * (NTSM_FAST_K - 1))) - 1), NTSM_FAST_K - 1, NTSM_FAST_M, NTSM_FAST_K - NTSM_FAST_M, 0);
-				} else {
-					const uint32_t mz = insert(x, plan.k, plan.m, plan.w, plan.a);
-					if (c->two_level) site_mz[i] = mz;
-				}
 			}
 			if (c->two_level) {
 				/* Bloom over the DISTINCT site minimizers: one 32-bit word per minimizer, two bits; 12 bits per distinct
@@ -1448,9 +1359,7 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.pf_shift = 32 - (c->prefilter_log2 - 5);
 	p.blk_bytes = (uint32_t) (c->n_blocks * 16);
 	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k, c->two_level);
-	/* pair form: its filter holds 18-mers, which the per-read (-m) instantiation does not read -- the crossing chunk of an
-	 * armed batch goes to the generic kernel's per-read form instead */
-	const bool fast = plan.mode >= 0 && c->d_blocks && c->kernel_variant != 1 && !(c->pair_mode && per_read);
+	const bool fast = plan.mode >= 0 && c->d_blocks && c->kernel_variant != 1;
 	p.bloom = c->d_bloom;
 	p.bloom_words = c->n_bloom_words;
 	p.fk_k = plan.k; p.fk_m2 = 2 * plan.m; p.fk_a2 = 2 * plan.a;
@@ -1595,9 +1504,7 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 #define NTSM_MZ2_CASE(M_) \
 		case 2 * M_: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, false, kFastC, true>), g, b, 0, st, p); break; \
 		case 2 * M_ + 1: hipLaunchKernelGGL((ntsm_count_mz_kernel<M_, true, kFastC, true>), g, b, 0, st, p); break;
-		if (c->pair_mode) {
-			hipLaunchKernelGGL((ntsm_count_mz_kernel<0, false, kFastC, false, true>), g, b, 0, st, p);
-		} else if (c->two_level) {
+		if (c->two_level) {
 			switch (plan.mode * 2 + (per_read ? 1 : 0)) {
 			NTSM_MZ2_CASE(0) NTSM_MZ2_CASE(2) NTSM_MZ2_CASE(3) NTSM_MZ2_CASE(4) NTSM_MZ2_CASE(5) NTSM_MZ2_CASE(6) NTSM_MZ2_CASE(7) NTSM_MZ2_CASE(8) NTSM_MZ2_CASE(9)
 			default: return NTSM_ERR_STATE;
@@ -2400,19 +2307,19 @@ int ntsm_rccl_probe(void) { return rccl_bind().ok ? NTSM_OK : NTSM_ERR_RCCL; }
 
 int ntsm_set_kernel(ntsm_ctx *c, int variant)
 {
-	if (!c || variant < 0 || variant > 5) return NTSM_ERR_ARG;
+	if (!c || variant < 0 || variant > 4) return NTSM_ERR_ARG;
 #ifndef NTSM_WITH_TAB
 	if (variant == 3) return NTSM_ERR_ARG;                 /* the tabulated kernel is not part of this build (make tab) */
 #endif
 	if (variant == 4 && ntsm_fast_plan((uint32_t) c->k, true).m != NTSM_TWO_M) return NTSM_ERR_ARG;   /* 15 <= k <= 31 */
-	if (variant == 5 && c->k != NTSM_FAST_K) return NTSM_ERR_ARG;
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
 	const int before = c->kernel_variant;
 	c->kernel_variant = variant;
-	/* the forms of the kernel read different tables (12-mer / 14-mer minimizers, k-mers / shared 18-mers): a change of form rebuilds them */
-	const FilterMode want = filter_mode_for(c, variant, c->filter_log2_req);
-	if (want.two_level != c->two_level || want.pair != c->pair_mode) {
+	/* one-level and two-level filters are different tables (12-mer / 14-mer minimizers): a change of level rebuilds them */
+	const bool want_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && variant != 1 && variant != 3 &&
+		(variant == 4 || (variant == 0 && c->filter_log2_req == 0 && ntsm_wants_two_level(c->n_kmers)));
+	if (variant != 1 && variant != 3 && want_two != c->two_level) {
 		HIPCHK(hipSetDevice(c->device));
 		rc = build_tables(c, c->filter_log2_req);
 		if (rc) { c->kernel_variant = before; return rc; }

@@ -142,12 +142,12 @@ def test_random_reads_vs_oracle_n10(nt, n10):
     _, _, ocnt = fp.kmers()
     # kernel variants (0 = minimizer-blocked fast path, 1 = generic, 4 = its two-level form with 14-mer minimizers and a
     # minimizer Bloom, which a set of this size would not take by itself) and filter / Bloom sizes must all agree
-    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (0, 124), (4, 0), (4, 214), (4, 266), (4, 22), (2, 0), (5, 0), (5, 20), (5, 124)):
+    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (0, 124), (4, 0), (4, 214), (4, 266), (4, 22)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         if flog:
             ctx.set_tuning(flog, 0)
-        st = ctx.debug_stats()                               # 2 / 5: one level, a test per position / per pair of positions
+        st = ctx.debug_stats()
         assert st["two_level"] == (variant == 4) and (st["bloom_words"] > 0) == (variant == 4), st
         if (variant, flog) == (4, 214):
             assert st["bloom_words"] == (1 << 14) // 32 and 300_000 < st["site_minimizers"] < len(sites.keys)
@@ -327,10 +327,10 @@ def test_early_stop_resident_and_batched(nt, n10):
         assert fp.max_hits == thr
         fp.process_flat(bases, ends)
         assert fp.early_term
-        for n_batches in (1, 7, -7, -3):                    # -7: the two-level form of the kernel (and of its per-read variant)
+        for n_batches in (1, 7, -7):                        # -7: the two-level form of the kernel (and of its per-read variant)
             ctx = nt.Context(sites.keys, max_hits=thr)
             if n_batches < 0:
-                ctx.set_kernel(4 if n_batches == -7 else 5)      # -3: the pair form (its crossing chunk goes to the generic per-read kernel)
+                ctx.set_kernel(4)
                 n_batches = -n_batches
             per = -(-n // n_batches)
             for b in range(n_batches):
@@ -1031,7 +1031,7 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
         fp.L.ntsm_oracle_fp_insert_count(fp.h, buf.tobytes(), n)
         ends = np.array([n], dtype=np.uint64)
         flat = np.concatenate([buf, np.frombuffer(b"N", dtype=np.uint8)])
-        for variant in (0, 1) + ((4, 2, 5) if k == 19 else ()):     # 4: two levels; 2 / 5: one level, test per position / per pair
+        for variant in (0, 1) + ((4,) if k == 19 else ()):     # 4: the two-level form of the k = 19 kernel
             ctx = nt.Context(sites.keys, k=k)
             ctx.set_kernel(variant)
             ctx.submit(flat, ends)
