@@ -63,6 +63,7 @@ _sig(H, "ntsm_lane_open", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTE
 _sig(H, "ntsm_lane_acquire", C.c_int, [C.c_void_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p])
 _sig(H, "ntsm_lane_submit", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32])
 _sig(H, "ntsm_lane_close", C.c_int, [C.c_void_p])
+_sig(H, "ntsm_lane_open_packed", C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)])
 _sig(H, "ntsm_lane_acquire_packed", C.c_int, [C.c_void_p, C.POINTER(u8p), C.POINTER(u8p), u64p])
 _sig(H, "ntsm_lane_submit_packed", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64])
 _sig(H, "ntsm_warmup", C.c_int, [C.c_int, C.c_int])
@@ -252,9 +253,9 @@ class Context:
         read_end = np.ascontiguousarray(read_end, dtype=np.uint64)
         _chk(H.ntsm_submit(self._h, _p(bases, u8p), bases.size, _p(read_end, u64p), read_end.size), "ntsm_submit")
 
-    def open_lane(self, cap_bytes=0, cap_reads=0):
+    def open_lane(self, cap_bytes=0, cap_reads=0, packed_only=False):
         """A producer lane (ntsm_lane_*): one host thread's private staging into this context."""
-        return Lane(self, cap_bytes, cap_reads)
+        return Lane(self, cap_bytes, cap_reads, packed_only)
 
     def set_max_hits(self, max_hits, armed=True):
         _chk(H.ntsm_set_max_hits(self._h, int(max_hits), int(bool(armed))), "ntsm_set_max_hits")
@@ -328,10 +329,13 @@ class Context:
 
 
 class Lane:
-    def __init__(self, ctx, cap_bytes=0, cap_reads=0):
+    def __init__(self, ctx, cap_bytes=0, cap_reads=0, packed_only=False):
         self._h = C.c_void_p()
         self._ctx = ctx                                   # keeps the context alive
-        _chk(H.ntsm_lane_open(ctx._h, cap_bytes, cap_reads, C.byref(self._h)), "ntsm_lane_open")
+        if packed_only:
+            _chk(H.ntsm_lane_open_packed(ctx._h, cap_bytes, C.byref(self._h)), "ntsm_lane_open_packed")
+        else:
+            _chk(H.ntsm_lane_open(ctx._h, cap_bytes, cap_reads, C.byref(self._h)), "ntsm_lane_open")
 
     def submit(self, bases, read_end):
         """acquire + copy + submit; the batch must fit the lane's slot."""

@@ -65,7 +65,7 @@ Feeder::Feeder(const Options &opt, ntsm_ctx *ctx, uint64_t max_hits, bool lane) 
 
 void Feeder::openLane()
 {
-	int rc = ntsm_lane_open(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16, &m_lane);
+	int rc = m_packed ? ntsm_lane_open_packed(m_ctx, m_cfgBytes, &m_lane) : ntsm_lane_open(m_ctx, m_cfgBytes, m_cfgBytes / 64 + 16, &m_lane);
 	if (rc) die(rc, "cannot open a producer lane");
 }
 
@@ -208,7 +208,8 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 		const bool maybe_armed = m_opt.covThresh != 0 && m_opt.covThresh < 1e300;
 		const bool lanes = m_opt.threads > 1 && !maybe_armed;
 		const uint64_t slot = std::max<uint64_t>(4096, m_opt.batch_bytes);
-		const uint64_t pool_bytes = lanes ? (uint64_t) m_opt.threads * 2 * (std::min<uint64_t>(slot, lane_bytes(m_opt.threads)) + 8192)
+		const uint64_t lane_slot = std::min<uint64_t>(slot, lane_bytes(m_opt.threads));
+		const uint64_t pool_bytes = lanes ? (uint64_t) m_opt.threads * 2 * ((m_opt.pack ? lane_slot * 3 / 8 : lane_slot) + 8192)   /* packed lanes pin 3/8 byte per position */
 		                                  : 2 * (slot + 8192 + (slot / 64 + 16) * 8 + 8192);
 		const int lanes_per_dev = lanes ? (int) ((m_opt.threads + m_ctxDevice.size() - 1) / m_ctxDevice.size()) : 0;
 		for (size_t i = 0; i < m_ctxDevice.size(); ++i) {

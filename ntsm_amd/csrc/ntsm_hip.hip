@@ -987,12 +987,16 @@ struct ntsm_lane {
 	Slot slot[2];
 	int next_slot = 0;
 	uint64_t cap_bytes = 0, cap_reads = 0;
+	bool packed_only = false;                  /* ntsm_lane_open_packed: pinned slots of 3/8 byte per position, no byte batches */
 	uint64_t total_bases = 0, reads_consumed = 0;     /* folded into the context by ntsm_lane_close */
 };
 
 namespace {
 
-int build_tables(ntsm_ctx *c, int filter_log2_req)
+/* Host part first (no HIP call: ntsm_create runs it while another thread may still be bringing the runtime up -- 0.2 s on
+ * this stack, during which every HIP call of this thread would only wait), then `before_upload` (ntsm_create: device checks
+ * and hipSetDevice), then the uploads. */
+int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx *) = nullptr)
 {
 	const uint32_t n = c->n_kmers;
 	/* The four structures are independent functions of the key set: built on four host threads (the cuckoo table
@@ -1212,6 +1216,10 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 		t1.join(); t2.join(); t3.join(); t4.join();
 	}
 	if (cuckoo_rc) return cuckoo_rc;
+	if (before_upload) {
+		const int rc0 = before_upload(c);
+		if (rc0) return rc0;
+	}
 	/* upload */
 	if (c->d_blocks) (void) hipFree(c->d_blocks);
 	if (c->d_prefilter) (void) hipFree(c->d_prefilter);
@@ -1279,10 +1287,10 @@ int build_tables(ntsm_ctx *c, int filter_log2_req)
 	return NTSM_OK;
 }
 
-int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device)
+int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device, bool packed_only = false)
 {
 	s.ends_on_device = ends_on_device;
-	s.h_bases_bytes = cap_bytes + 64;
+	s.h_bases_bytes = (packed_only ? (cap_bytes & ~31ull) / 4 + (cap_bytes & ~31ull) / 8 : cap_bytes) + 64;   /* packed: 3/8 byte per position */
 	s.h_ends_bytes = cap_reads * sizeof(uint64_t);
 	s.h_bases = (uint8_t *) pool_alloc(s.h_bases_bytes);
 	if (!s.h_bases) HIPCHK(hipHostMalloc(&s.h_bases, s.h_bases_bytes, hipHostMallocPortable));
@@ -1752,13 +1760,7 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 	if (!out || k < 1 || k > 32 || (n_kmers && !keys)) return NTSM_ERR_ARG;
 	if (key_kind != NTSM_KEYS_CANONICAL && key_kind != NTSM_KEYS_HASH64) return NTSM_ERR_ARG;
 	*out = nullptr;
-	int n_dev = 0;
-	hipError_t e = hipGetDeviceCount(&n_dev);
-	if (e != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
-		g_last_hip = (int) e;
-		return NTSM_ERR_NO_DEVICE;
-	}
-	HIPCHK(hipSetDevice(device));
+	if (device < 0) return NTSM_ERR_NO_DEVICE;
 	ntsm_ctx *c = new (std::nothrow) ntsm_ctx();
 	if (!c) return NTSM_ERR_NOMEM;
 	c->device = device;
@@ -1768,16 +1770,28 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 	c->armed = max_hits != 0;
 	c->mask = mask_for_k(k);
 	memset(c->ev_used, 0, sizeof c->ev_used);
-	hipDeviceProp_t prop;
-	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-		c->n_cu = prop.multiProcessorCount;
 	c->canon.resize(n_kmers);
 	for (uint32_t i = 0; i < n_kmers; ++i) {
 		uint64_t x = key_kind == NTSM_KEYS_HASH64 ? ntsm_hash64_inv(keys[i], k) : keys[i];
 		if (x & ~c->mask && k < 32) { delete c; return NTSM_ERR_ARG; }
 		c->canon[i] = x;
 	}
-	int rc = build_tables(c, 0);
+	/* The tables are built on the host BEFORE the first HIP call of this function: a caller that warms the runtime up on a
+	 * side thread (ntsm_warmup) gets the 50-60 ms of table construction for free while the runtime initialises. */
+	int rc = build_tables(c, 0, [](ntsm_ctx *cc) -> int {
+		int n_dev = 0;
+		hipError_t e = hipGetDeviceCount(&n_dev);
+		if (e != hipSuccess || n_dev <= 0 || cc->device >= n_dev) {
+			g_last_hip = (int) e;
+			return NTSM_ERR_NO_DEVICE;
+		}
+		HIPCHK(hipSetDevice(cc->device));
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, cc->device) == hipSuccess && prop.multiProcessorCount > 0)
+			cc->n_cu = prop.multiProcessorCount;
+		return NTSM_OK;
+	});
+	if (rc == NTSM_ERR_NO_DEVICE || rc == NTSM_ERR_DUP_KEY || rc == NTSM_ERR_ARG) { delete c; return rc; }   /* nothing on the device yet */
 	if (rc) { ntsm_destroy(c); return rc; }
 	uint8_t lut[256];
 	build_lut(lut);
@@ -1928,7 +1942,12 @@ int ntsm_staging_pool(uint64_t bytes)
 	return NTSM_OK;
 }
 
-int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lane **out)
+static int lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, bool packed_only, ntsm_lane **out);
+
+int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lane **out) { return lane_open(c, cap_bytes, cap_reads, false, out); }
+int ntsm_lane_open_packed(ntsm_ctx *c, uint64_t cap_positions, ntsm_lane **out) { return lane_open(c, cap_positions, 16, true, out); }
+
+static int lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, bool packed_only, ntsm_lane **out)
 {
 	if (!c || !out) return NTSM_ERR_ARG;
 	*out = nullptr;
@@ -1942,6 +1961,7 @@ int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lan
 	l->c = c;
 	l->cap_bytes = cap_bytes;
 	l->cap_reads = cap_reads;
+	l->packed_only = packed_only;
 	/* Lanes do not own streams (creating one costs 14 ms): all lanes of a context share its two lane streams, round
 	 * robin.  Copies and kernels of different lanes interleave there in submission order; a lane only waits on the
 	 * events of its own slots. */
@@ -1956,7 +1976,7 @@ int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lan
 	for (int i = 0; i < 2; ++i) {
 		Slot &s = l->slot[i];
 		s.stream = st;
-		int rc = alloc_slot(s, c->device, cap_bytes, cap_reads, false);
+		int rc = alloc_slot(s, c->device, cap_bytes, cap_reads, false, packed_only);
 		if (rc) {
 			for (auto &q : l->slot) {
 				free_slot(q);
@@ -1978,6 +1998,7 @@ int ntsm_lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, ntsm_lan
 int ntsm_lane_acquire(ntsm_lane *l, uint8_t **bases, uint64_t *cap_bytes, uint64_t **read_end, uint64_t *cap_reads)
 {
 	if (!l || !bases || !cap_bytes || !read_end || !cap_reads) return NTSM_ERR_ARG;
+	if (l->packed_only) return NTSM_ERR_STATE;            /* its pinned slots hold packed batches only */
 	HIPCHK(hipSetDevice(l->c->device));
 	Slot &s = l->slot[l->next_slot];
 	int rc = wait_slot(s);

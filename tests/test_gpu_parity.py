@@ -927,9 +927,16 @@ def test_packed_lane_batches_vs_oracle(nt, tmp_path):
         with pytest.raises(nt.NtsmError):
             lane.submit_packed([b"A" * (2 << 20)])           # larger than the slot
         lane.close()
+        # a lane opened for packed batches only pins 3/8 byte per position and refuses byte batches
+        lane = ctx.open_lane(1 << 20, packed_only=True)
+        with pytest.raises(nt.NtsmError):
+            lane.submit(*nt.capi.flatten_reads(reads[:10]))
+        for b in range(0, len(reads), chunk):
+            lane.submit_packed(reads[b:b + chunk], force_scalar=force_scalar)
+        lane.close()
         t = ctx.sync()
-        assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (fp.total_kmers, fp.total_hits, fp.total_bases, len(reads))
-        assert np.array_equal(ctx.counts(), fp.kmers()[2])
+        assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (2 * fp.total_kmers, 2 * fp.total_hits, 2 * fp.total_bases, 2 * len(reads))
+        assert np.array_equal(ctx.counts(), 2 * fp.kmers()[2])
         ctx.close()
 
 
