@@ -327,14 +327,18 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 		 * fit one lane slot, so that no thread waits for its predecessor in the middle of a block */
 		if (!pf.open(fn, std::min<uint64_t>(m_opt.block_bytes, 2 * lane_bytes(m_opt.threads)))) { rest.push_back(fn); continue; }
 		const auto tp0 = std::chrono::steady_clock::now();
-		if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "block-parallel: " << pf.n_blocks() << " blocks, " << want << " threads" << std::endl;
+		if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "block-parallel: " << pf.n_blocks() << " blocks, " << std::min<size_t>(want, 16) << " threads" << std::endl;
 		std::vector<Feeder *> sinks;
+		/* One plain FASTQ is parsed by at most 16 threads however many -t asks for: measured on a 256-thread host, 16
+		 * feeders parse + count at 50 Gbases/s, 32 at 40, 64 at 25 (they queue up on the runtime's submission path and on
+		 * the memory of the socket that holds the page cache); the result does not depend on the number. */
+		const size_t n_par = std::min<size_t>(want, 16);
 		{
 			std::vector<std::thread> mk;                         /* lanes (pinned staging) are allocated in parallel */
-			for (size_t t = 0; t < want; ++t) mk.emplace_back([this, t]() { (void) feederFor(t); });
+			for (size_t t = 0; t < n_par; ++t) mk.emplace_back([this, t]() { (void) feederFor(t); });
 			for (auto &th : mk) th.join();
 		}
-		for (size_t t = 0; t < want; ++t) sinks.push_back(&feederFor(t));
+		for (size_t t = 0; t < n_par; ++t) sinks.push_back(&feederFor(t));
 		const auto tp1 = std::chrono::steady_clock::now();
 		const ParallelFastq::Result r = pf.run(sinks);
 		const auto tp2 = std::chrono::steady_clock::now();
