@@ -294,6 +294,8 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
     wall, p = best
     os.unlink(fq)
     phases = [l[8:] for l in p.stderr.decode().split("\n") if l.startswith("[phase]")]
+    own = [l for l in p.stderr.decode().split("\n") if l.startswith("Time: ")]          # the CLI's own clock, main() to the last print
+    cli_s = float(own[-1].split()[1]) if own else None
     parse_s = None
     for l in phases:
         if "parse+count" in l:
@@ -318,6 +320,7 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
     bases = n_reads * READ_LEN
     return {"workload": "build/ntsmCount -t %d on one plain FASTQ of %.3g reads (%.1f GB, page cache), hs_n10_like sites" % (args.e2e_threads, n_reads, size / 1e9),
             "reads": n_reads, "file_bytes": size, "wall_s": wall, "gbases_per_s": bases / wall / 1e9,
+            "cli_reported_s": cli_s,       # inside the process; wall_s also holds its spawn from this (large) parent and its exit
             "parse_and_count_s": parse_s, "gbases_per_s_parse_and_count": bases / parse_s / 1e9 if parse_s else None,
             "phases": phases, "fastq_gen_s": t_gen, "counts_sha256": sha_cli, "check": {"counts_txt_equals_resident_path": True}}
 
