@@ -129,7 +129,21 @@ void Feeder::feedFile(const std::string &fn, uint64_t offset)
 	while (l >= 0 && !m_earlyTerm) {
 		feedRead(rd.seq_data(), (uint64_t) l);
 		l = rd.next();
+		/* -vvv: "Current Total" after every 1,000,000th read (src/FingerPrint.hpp:70-78: m_totalReads only advances at this
+		 * verbosity, after the read has been processed and the next one fetched).  The totals have to be those after exactly
+		 * that many reads, so the batch is submitted and waited for here -- a debugging verbosity, run on one thread. */
+		if (m_opt.verbose > 2 && !m_useLane && (++m_totalReads % 1000000) == 0) progressLine();
 	}
+}
+
+void Feeder::progressLine()
+{
+	flush();                                               /* may trip the -m threshold: the line is printed all the same, like the reference's */
+	ntsm_totals t;
+	int rc = ntsm_sync(m_ctx, &t);
+	if (rc) die(rc, "sync failed");
+	std::cerr << "Current Total: " << m_totalReads << " reads, " << t.total_kmers << " k-mers, " << t.total_hits
+	          << " total counts, and " << t.total_bases << " total bases " << std::endl;
 }
 
 /* one read into a packed lane: the same slot logic as below, in positions */
@@ -206,7 +220,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 	const auto tc0 = std::chrono::steady_clock::now();
 	{
 		const bool maybe_armed = m_opt.covThresh != 0 && m_opt.covThresh < 1e300;
-		const bool lanes = m_opt.threads > 1 && !maybe_armed;
+		const bool lanes = m_opt.threads > 1 && !maybe_armed && m_opt.verbose <= 2;
 		const uint64_t slot = std::max<uint64_t>(4096, m_opt.batch_bytes);
 		const uint64_t lane_slot = std::min<uint64_t>(slot, lane_bytes(m_opt.threads));
 		const uint64_t pool_bytes = lanes ? (uint64_t) m_opt.threads * 2 * ((m_opt.pack ? lane_slot * 3 / 8 : lane_slot) + 8192)   /* packed lanes pin 3/8 byte per position */
@@ -301,7 +315,8 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 	 * index; the counts meet in the context's table (one context per device with -g a,b: summed at the end).
 	 * With -m the reference's parallel schedule is a race; the only defined semantics is
 	 * argv order on one thread, which is what an armed run always uses. */
-	const size_t want = m_maxCounts != 0 ? 1 : std::max(1u, m_opt.threads);
+	/* -vvv prints running totals at exact read counts (Feeder::progressLine): one ordered stream as well */
+	const size_t want = m_maxCounts != 0 || m_opt.verbose > 2 ? 1 : std::max(1u, m_opt.threads);
 	/* BGZF (bgzip) input is inflated block-parallel: share the -t threads among the files that are read at once */
 	GzStream::set_decoder_threads((unsigned) std::max<size_t>(1, m_opt.threads / std::max<size_t>(1, std::min(want, filenames.size()))));
 	if (!m_prep.empty()) {

@@ -68,6 +68,8 @@ public:
 
 private:
 	[[noreturn]] void die(int rc, const char *what) const;
+	void progressLine();                       /* -vvv: "Current Total: ..." (src/FingerPrint.hpp:70-78) */
+	uint64_t m_totalReads = 0;                 /* the reference's m_totalReads: advanced under -vvv only */
 	const Options &m_opt;
 	void openLane();
 	ntsm_ctx *m_ctx = nullptr;

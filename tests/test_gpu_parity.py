@@ -1120,6 +1120,26 @@ def test_resident_stream_beyond_4gib(nt, n10):
     del d
 
 
+def test_cli_vvv_progress_lines(nt, tmp_path):
+    """-vvv: "Current Total: N reads, ... k-mers, ... total counts, and ... total bases " after every 1,000,000th read
+    (src/FingerPrint.hpp:70-78), and the "max count reached at N reads" line with the reference's N under -m: byte for byte
+    what the compiled reference printed for the same seeded input (tests/golden/vvv_progress.json, made by
+    tests/golden/make_vvv.py); stdout is the same as without -v."""
+    gold = json.load(open(os.path.join(G, "vvv_progress.json")))
+    pr = gold["params"]
+    sp, fq = str(tmp_path / "s.fa"), str(tmp_path / "r.fq")
+    s = nt.SynthShort(pr["sites_seed"], pr["n_sites"], read_seed=pr["read_seed"], p_embed=pr["p_embed"], sites_path=sp)
+    s.write_fastq(fq, 0, pr["n_reads"], threads=8)
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    for case in gold["cases"]:
+        p = subprocess.run([exe, "-s", sp, "-v", "-v", "-v", "-t", "4"] + case["extra"] + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr[-400:]
+        lines = [l for l in p.stderr.decode().split("\n") if l.startswith(("Current Total:", "max count reached", "Reached desired"))]
+        assert lines == case["lines"], (case["extra"], lines)
+        q = subprocess.run([exe, "-s", sp, "-t", "4"] + case["extra"] + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert q.returncode == 0 and q.stdout == p.stdout and _summary(q.stderr) == _summary(p.stderr)
+
+
 def test_cli_clean_exit_runs_the_destructors(nt):
     """The CLI leaves with _exit once everything is printed (process teardown of a HIP program costs ~0.13 s);
     NTSM_CLEAN_EXIT=1 takes the ordinary way out -- lanes, contexts, streams and the pinned pool are destroyed -- and must
