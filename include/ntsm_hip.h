@@ -177,7 +177,8 @@ int ntsm_reset(ntsm_ctx *ctx);
 int ntsm_set_timing(ntsm_ctx *ctx, int on);
 int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
 /* Tuning knobs (0 = automatic): log2 of filter bits (rebuilds the tables: counts and totals restart from zero; 100 + v =
- * 3 * 2^v bits; 200 + v / 250 + v = size of the two-level path's minimizer Bloom, 2^v / 3 * 2^v bits), grid blocks.
+ * 3 * 2^v bits; 2000000 + w = w KiB; 200 + v / 250 + v / 1000000 + w = size of the two-level path's minimizer Bloom, 2^v /
+ * 3 * 2^v bits / w KiB), grid blocks.
  * For profiling experiments. */
 int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
 /* An armed (-m) batch is walked in chunks of about chunk_bytes of stream (at most 2^20 reads, at least 1024) so that the work

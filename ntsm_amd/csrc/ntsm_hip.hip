@@ -52,6 +52,9 @@ namespace {
 #ifndef NTSM_STREAM_NT
 #define NTSM_STREAM_NT 1                                /* read stream: non-temporal loads (read once) */
 #endif
+#if NTSM_STREAM_NT && !defined(NTSM_STREAM_AUX)
+#define NTSM_STREAM_AUX 2                               /* minimizer-blocked kernels, interior tiles: buffer loads with the nt bit */
+#endif
 constexpr int kThreads = 256;
 constexpr uint32_t kN4 = 0x4E4E4E4Eu;      /* "NNNN" */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -336,10 +339,18 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		if (ts >= p.lo && ts + kThreads * C <= p.hi) {
 			/* interior tile: plain coalesced loads (the boundary logic of ntsm_load_vec costs ~100 VALU instructions per
 			 * vector, 6.5 per base position -- a sixth of this kernel's instruction count when it ran for every tile) */
+#ifdef NTSM_STREAM_AUX
+			/* the tile through a buffer descriptor of its own (scalar base, 32-bit lane offsets, cache-policy bits in the
+			 * instruction): nt keeps the read-once stream from displacing the filter in the L2 -- without it the kernel runs 8 %
+			 * slower (830 against 904 Gbases/s), and the buffer form is 0.8 % faster than a non-temporal global load (911) */
+			const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.base + ts), (short) 0, kThreads * C, 0x00020000);
+#endif
 #pragma unroll
 			for (int q = 0; q < VPT; ++q) {
 				const int v = t + kThreads * q;
-#if NTSM_STREAM_NT
+#ifdef NTSM_STREAM_AUX
+				const ntsm_u32x4 nt = __builtin_amdgcn_raw_buffer_load_b128(st_rsrc, 16 * v, 0, NTSM_STREAM_AUX);
+#elif NTSM_STREAM_NT
 				const u32x4 nt = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p.base + ts + 16ll * v));
 #else
 				const u32x4 nt = *reinterpret_cast<const u32x4 *>(p.base + ts + 16ll * v);
@@ -775,7 +786,9 @@ namespace {
 
 constexpr int kTileC = 128;                 /* stream bytes per thread and tile */
 #ifndef NTSM_TABLE_LOAD
-#define NTSM_TABLE_LOAD 0.4                    /* cuckoo key table: slots >= keys / load, power of two */
+#define NTSM_TABLE_LOAD 0.25                   /* cuckoo key table: slots >= keys / load, power of two.  A sparser table costs memory, not time
+                                                * (the Infinity Cache holds 128 MiB as well as 64): what a fuller one costs is the second-bucket probe of
+                                                * a key whose first bucket is full -- 903 / 889 / 856 / 833 Gbases/s at load <= 0.25 / 0.4 / 0.6 / 0.8 */
 #endif
 #ifdef NTSM_WITH_TAB
 #ifndef NTSM_TAB_SEG_TILES
@@ -928,6 +941,8 @@ struct ntsm_ctx {
 	bool two_level = false;                    /* k = 19 and the blocked filter would not fit the L2: 14-mer minimizers + d_bloom */
 	uint32_t n_site_minimizers = 0;            /* distinct minimizers of the site k-mers (two-level path only) */
 	uint32_t bloom_words_req = 0;              /* tuning: Bloom size in words (0 = automatic) */
+	uint32_t blocks_kib_req = 0;               /* tuning: blocked filter size in KiB (0 = automatic / filter_log2_req) */
+	uint32_t prefilter_log2_req = 0;           /* tuning: log2 of the drain Bloom's bits (0 = automatic) */
 	bool prefilter_forced = false;             /* tuning (code 2): keep the drain's Bloom on the two-level path as well */
 	int filter_log2_req = 0;                   /* tuning: what ntsm_set_tuning asked for (kept across rebuilds) */
 	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
@@ -1005,7 +1020,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 	std::vector<uint32_t> filter, blocks /* 4 words per block */, prefilter;
 	int cuckoo_rc = NTSM_OK;
 	auto build_cuckoo = [&]() {
-		/* slots: power of two with load <= 0.4; at least 32 */
+		/* slots: power of two with load <= NTSM_TABLE_LOAD; at least 32 */
 		uint64_t slots = 32;
 		while ((double) n > NTSM_TABLE_LOAD * (double) slots) slots <<= 1;
 		for (;; slots <<= 1) {
@@ -1094,6 +1109,17 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 			if (e > 22) e = 22;
 			if (e < 4) e = 4;
 			c->n_blocks = (uint64_t) mult << e;
+			if (filter_log2_req == 0 && !c->two_level) {
+				/* One level, automatic: the index is a multiply-high range reduction, so the size need not be 2^e or 3 * 2^e.
+				 * 13.5 bits per key in steps of 64 KiB, at most 3 MiB: the filter shares the 4 MiB L2 with the stream and the
+				 * look-ups' lines, and past ~2.75 MiB every further bit per key is paid for in L2 misses.  Measured on the bench
+				 * set (1.54 M keys, 3e8 reads; 2 / 2.25 / 2.375 / 2.5 / 2.625 / 2.75 / 3 MiB): 862 / 883 / 888 / 891 / 888 / 885 /
+				 * 863 Gbases/s; 2.08 M keys: 3 MiB 777, 3.25 770; 2.56 M keys: 3 / 3.25 / 3.5 / 3.75 / 4 MiB: 718 / 721 / 722 / 711 / 716. */
+				const uint64_t kib = std::min<uint64_t>(3072, std::max<uint64_t>(1, (27ull * n / 16 + 1023) / 1024));   /* 13.5 bits = 27/16 bytes per key */
+				c->n_blocks = std::max<uint64_t>(16, ((kib + 63) / 64 * 64) * 64);
+				if (kib < 64) c->n_blocks = std::max<uint64_t>(16, kib * 64);
+			}
+			if (c->blocks_kib_req) c->n_blocks = (uint64_t) c->blocks_kib_req * 64;   /* tuning: any size, the index is a multiply-high range reduction */
 			c->blk_map.n_blocks = (uint32_t) c->n_blocks;
 			blocks.assign(c->n_blocks * 4, 0u);
 			std::vector<uint32_t> site_mz;                            /* two-level path: every site k-mer's minimizer */
@@ -1153,6 +1179,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 			 * set: always an L2 hit, always passes). */
 			const bool pass_all = c->two_level && !c->prefilter_forced;
 			while (!pass_all && pl < 28 && (1ull << pl) < 5ull * n) ++pl;
+			if (c->prefilter_log2_req && !pass_all) pl = c->prefilter_log2_req;
 #ifdef NTSM_ABLATION
 			if (const char *ev = getenv("NTSM_PREFILTER_LOG2")) pl = (uint32_t) atoi(ev);
 #endif
@@ -2279,6 +2306,15 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
 	c->grid_blocks = grid_blocks;
+	if (filter_log2_bits >= 3000000 && filter_log2_bits < 3000040) {   /* 3000000 + v: drain Bloom of 2^v bits (0: automatic again) */
+		c->prefilter_log2_req = (uint32_t) (filter_log2_bits - 3000000);
+		if (c->prefilter_log2_req && (c->prefilter_log2_req < 10 || c->prefilter_log2_req > 30)) { c->prefilter_log2_req = 0; return NTSM_ERR_ARG; }
+		filter_log2_bits = 1000000 + (int) (c->bloom_words_req / 256u);     /* falls into the rebuild below */
+	}
+	if (filter_log2_bits >= 2000000 && filter_log2_bits < 3000000) {   /* 2000000 + w: blocked filter of w KiB (0: automatic again) */
+		c->blocks_kib_req = (uint32_t) (filter_log2_bits - 2000000);
+		filter_log2_bits = 1000000 + (int) (c->bloom_words_req / 256u);     /* falls into the rebuild below */
+	}
 	if (filter_log2_bits == 2 || filter_log2_bits == 3) {       /* 2 / 3: two-level path with / without the drain's Bloom (default: without) */
 		c->prefilter_forced = filter_log2_bits == 2;
 		filter_log2_bits = 1000000 + (int) (c->bloom_words_req / 256u);     /* falls into the rebuild below (0 words = automatic) */
