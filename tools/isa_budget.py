@@ -28,7 +28,7 @@ def main():
         t = line.strip()
         if cur and t and not t.startswith((".", ";")):
             blocks[cur].append(t.split(";")[0].strip())
-    main_blk = max(blocks, key=lambda b: sum(1 for i in blocks[b] if i.startswith("buffer_load_dwordx4")))
+    main_blk = max(blocks, key=lambda b: sum(1 for i in blocks[b] if i.startswith("buffer_load_dwordx4") and "idxen" in i))   # the filter-block loads (the stream loads are buffer loads too, without idxen)
     ins = blocks[main_blk]
     unit = collections.Counter(); mnem = collections.Counter()
     for i in ins:
