@@ -7,8 +7,8 @@ One "step" = one pass of the count path over the whole resident workload (BASELI
 N > 1 (configs[3]): one rank per GPU, every rank owns its own 1e9 reads (weak scaling); each step ends with one
 RCCL SUM of the per-k-mer count vector + totals.  The ranks are started either by torch.distributed.run
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE in the
-environment) or by this script itself: `python bench.py --gpus N` with no WORLD_SIZE spawns N fresh child processes
-BEFORE anything in the parent touches the GPU, one per device, and passes rank 0's JSON line through.  A request for
+environment) or by this script itself: `python bench.py --gpus N` with no WORLD_SIZE spawns N fresh child processes,
+one per device, and passes rank 0's JSON line through; the parent never loads torch or HIP (it counts devices in sysfs).  A request for
 more GPUs than the box has, or a WORLD_SIZE that differs from --gpus, ends with a non-zero exit status and no JSON
 line -- never an N = 1 line for an N > 1 request.
 
@@ -66,12 +66,42 @@ def parse_args(argv=None):
 # N > 1 without a launcher: spawn the ranks ourselves.  Nothing here may initialise the GPU (a process that has must
 # not be replaced or forked into ranks): the parent only counts devices and starts children.
 # -----------------------------------------------------------------------------------------------------------------
+def count_gpus_without_hip():
+    """Number of GPUs this process may use, WITHOUT loading the HIP runtime (the launcher parent must stay a process that
+    never initialised the GPU): KFD topology nodes with SIMDs (else DRM render nodes), narrowed by the *_VISIBLE_DEVICES
+    lists.  None when neither source is readable -- the ranks then find out themselves (run_rank returns 3)."""
+    import glob
+    have = None
+    if not os.path.exists("/dev/kfd"):
+        have = 0                                         # no amdgpu compute driver at all: nothing a rank could open
+    else:
+        try:
+            n = 0
+            for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+                for line in open(f):
+                    kv = line.split()
+                    if len(kv) == 2 and kv[0] == "simd_count" and int(kv[1]) > 0:
+                        n += 1
+            have = n if n else None
+        except (OSError, ValueError):
+            have = None
+        if have is None:
+            rn = glob.glob("/dev/dri/renderD*")
+            have = len(rn) if rn else None
+    if have is None:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
 def launch_ranks(args, argv):
     n = args.gpus
     if not args.dry_launch:
-        import torch                                     # device_count() does not create a GPU context
-        have = torch.cuda.device_count()
-        if have < n:
+        have = count_gpus_without_hip()                  # no torch / HIP in this process: it only starts children
+        if have is not None and have < n:
             sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to run a smaller job "
                              "under that name\n" % (n, have))
             return 3
@@ -335,6 +365,7 @@ def run_rank(args):
                           "pid": os.getpid(), "ppid": os.getppid()}), flush=True)
         return 0
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     import ntsm_amd
@@ -343,7 +374,8 @@ def run_rank(args):
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the count path has no CPU fallback")
     if local >= torch.cuda.device_count():
-        sys.stderr.write("bench.py: rank %d wants device %d but this node exposes %d GPU(s)\n" % (rank, local, torch.cuda.device_count()))
+        sys.stderr.write("bench.py: rank %d wants device %d but this node exposes %d GPU(s); refusing to run a smaller job under that name\n"
+                         % (rank, local, torch.cuda.device_count()))
         return 3
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -378,18 +410,29 @@ def run_rank(args):
     n_bytes = d_bases.numel()
     bases_per_step = n_reads * READ_LEN
 
+    merge_s = [0.0, 0.0, 0.0]        # host seconds inside merge_counts: wait for own kernels + gather, all-reduce, import
+    payload_words = [0]
+
     def run_step():
         ctx.count_resident(d_bases.data_ptr(), n_bytes, 0, n_reads)
         if use_dist:
-            merge_counts(ctx)
+            payload_words[0] = merge_counts(ctx, times=merge_s)
 
     # Correctness of the timed launch at full size (byte offsets far beyond 2^32), independent of the kernel being timed:
     # the same resident stream counted by the GENERIC kernel (no minimizers, no blocked filter, its own rolling code) in
     # read-aligned pieces of < 2 GiB on a second context, each piece re-based so that its offsets are small.  The timed
     # context must reproduce these totals and per-k-mer counts exactly (checked after the timed region).  Oracle parity of
     # both kernels is the job of tests/test_gpu_parity.py.
+    # N > 1: EVERY rank does this for its own shard, and the job-wide expectation is formed over a route that shares
+    # nothing with the one being timed: the ranks' generic-kernel vectors are summed on the HOST through a gloo group
+    # (TCP over loopback, no RCCL, no device memory), their totals and SHA-256 travel by all_gather_object.
     expect = None
-    if not args.no_check and not use_dist:
+    expect_job = None
+    rank_info = None
+    gloo = None
+    if use_dist:
+        gloo = dist.new_group(backend="gloo")
+    if not args.no_check:
         ref = ntsm_amd.Context(sites.keys, k=K, device=local)
         if args.kernel != 1:
             ref.set_kernel(1)
@@ -400,6 +443,13 @@ def run_rank(args):
         tr = ref.sync()
         expect = (tr.total_kmers, tr.total_hits, ref.counts())
         ref.close()
+        if use_dist:
+            job_vec = torch.from_numpy(expect[2].view(np.int64).copy())
+            dist.all_reduce(job_vec, op=dist.ReduceOp.SUM, group=gloo)            # CPU tensors over gloo
+            rank_info = [None] * world
+            dist.all_gather_object(rank_info, {"rank": rank, "reads": n_reads, "first_read": rank * n_reads, "kmers": int(expect[0]), "hits": int(expect[1]),
+                                               "counts_sha256": hashlib.sha256(expect[2].tobytes()).hexdigest()}, group=gloo)
+            expect_job = (sum(r["kmers"] for r in rank_info), sum(r["hits"] for r in rank_info), job_vec.numpy().view(np.uint64))
 
     for _ in range(args.warmup):
         run_step()
@@ -407,6 +457,7 @@ def run_rank(args):
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
+    merge_s[:] = [0.0, 0.0, 0.0]
     ctx.set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -418,19 +469,44 @@ def run_rank(args):
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = ctx.get_timing()
     ctx.set_timing(False)
+    reps = args.steps + args.warmup
+    checked = merged_checked = False
+    merged_totals = None
+    if use_dist:
+        # what the last timed step's all-reduce left: the job-wide view (counts + totals) on every rank
+        merged_totals = ctx.sync()
+        merged_counts = ctx.counts()
+        if expect_job is not None:
+            assert (merged_totals.total_kmers, merged_totals.total_hits) == (reps * expect_job[0], reps * expect_job[1]), \
+                "rank %d: RCCL-merged totals %r differ from %d x the host-side (gloo) sum of the ranks' generic-kernel totals %r" \
+                % (rank, (merged_totals.total_kmers, merged_totals.total_hits), reps, expect_job[:2])
+            assert merged_totals.reads_consumed == reps * world * n_reads and merged_totals.total_bases == reps * world * bases_per_step, \
+                "rank %d: merged read / base totals are not those of %d ranks" % (rank, world)
+            assert (merged_counts == expect_job[2] * np.uint64(reps)).all(), \
+                "rank %d: RCCL-merged per-k-mer counts differ from the host-side (gloo) sum of the ranks' generic-kernel counts" % rank
+            merged_checked = True
+        ctx.set_max_hits(0, armed=False)                   # drop the merged view: this context's own counts again
     totals = ctx.sync()
-    checked = False
     if expect is not None:
-        reps = args.steps + args.warmup
         assert (totals.total_kmers, totals.total_hits) == (reps * expect[0], reps * expect[1]), \
             "timed launches disagree with the generic kernel's sum over < 2 GiB pieces: %r vs %d x %r" % ((totals.total_kmers, totals.total_hits), reps, expect[:2])
-        assert (ctx.counts() == expect[2] * reps).all(), "per-k-mer counts of the timed launches differ from the generic kernel's sum over pieces"
+        assert (ctx.counts() == expect[2] * np.uint64(reps)).all(), "per-k-mer counts of the timed launches differ from the generic kernel's sum over pieces"
         checked = True
 
+    per_rank = None
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        mine = {"rank": rank, "device": local, "elapsed_s": elapsed, "launches": n_launch, "avg_launch_ms": kernel_ms / max(n_launch, 1),
+                "wait_and_gather_ms_per_step": 1e3 * merge_s[0] / args.steps, "allreduce_ms_per_step": 1e3 * merge_s[1] / args.steps,
+                "import_ms_per_step": 1e3 * merge_s[2] / args.steps, "own_shard_equals_generic_kernel": checked,
+                "merged_equals_host_sum_of_all_ranks": merged_checked}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine, group=gloo)
         elapsed = float(tmax.item())
+        if rank_info is not None:
+            for a, b in zip(per_rank, rank_info):
+                a.update({"first_read": b["first_read"], "kmers_per_step": b["kmers"], "hits_per_step": b["hits"], "counts_sha256": b["counts_sha256"]})
     ctx.close()
     del d_bases
     torch.cuda.empty_cache()
@@ -438,6 +514,8 @@ def run_rank(args):
     if rank == 0:
         value = world * bases_per_step * args.steps / elapsed
         launch_s = kernel_ms / 1e3 / max(n_launch, 1)
+        if per_rank:                                       # N > 1: the roofline of the slowest GPU's kernel (every rank runs the same launch)
+            launch_s = max(r["avg_launch_ms"] for r in per_rank) / 1e3
         bytes_per_base = (READ_LEN + 8) / READ_LEN
         achieved = bases_per_step * bytes_per_base / launch_s / 1e9
         tj, traffic_note = pmc_constants(TRAFFIC_FILE, args.kernel in (0, 2))
@@ -471,12 +549,29 @@ def run_rank(args):
                          "algorithmic_bytes_per_base": bytes_per_base,
                          "valu_busy_frac_from_pmc": valu_busy,     # share of SIMD issue cycles on VALU
                          "l2_request_rate_frac_of_cap_from_pmc": l2_frac,   # the resource that binds: L2 requests/s over the measured 266 G/s cap
-                         "kmer_probe_rate_per_s": totals.total_kmers / max(args.steps + args.warmup, 1) / launch_s},
-            "check": {"total_kmers_per_step": totals.total_kmers // (args.steps + args.warmup) if world == 1 else None,
-                      "total_hits_per_step": totals.total_hits // (args.steps + args.warmup) if world == 1 else None,
+                         "kmer_probe_rate_per_s": totals.total_kmers / max(reps, 1) / launch_s,
+                         "per_gpu": world > 1},          # N > 1: one GPU's kernel (slowest rank's average launch), not the job
+            "check": {"total_kmers_per_step": totals.total_kmers // reps,        # this rank's own shard
+                      "total_hits_per_step": totals.total_hits // reps,
                       "equals_generic_kernel_sum_of_pieces_below_2GiB": checked,
                       "note": "independent-kernel consistency at full size; oracle parity of both kernels: tests/test_gpu_parity.py"},
         }
+        if use_dist:
+            # evidence that N ranks really merged: what the collective saw, what it cost, and the merge checked against a
+            # host-side sum that never touched RCCL (every rank asserted both before this line could be printed)
+            out["check"].update({
+                "every_rank_equals_generic_kernel_on_its_own_shard": bool(per_rank) and all(r["own_shard_equals_generic_kernel"] for r in per_rank),
+                "merged_equals_host_side_gloo_sum_of_all_ranks_generic_counts": bool(per_rank) and all(r["merged_equals_host_sum_of_all_ranks"] for r in per_rank),
+                "merged_total_kmers_per_step": merged_totals.total_kmers // reps, "merged_total_hits_per_step": merged_totals.total_hits // reps,
+                "merged_reads_per_step": merged_totals.reads_consumed // reps, "ranks_checked": len(per_rank or [])})
+            out["collective"] = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "library": "RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                                 "op": "all_reduce SUM int64[n_kmers + 4], once per step", "payload_bytes": 8 * payload_words[0],
+                                 "allreduce_ms_per_step": max(r["allreduce_ms_per_step"] for r in per_rank),
+                                 "wait_and_gather_ms_per_step": max(r["wait_and_gather_ms_per_step"] for r in per_rank),
+                                 "import_ms_per_step": max(r["import_ms_per_step"] for r in per_rank),
+                                 "check_route": "gloo (host TCP) all_reduce of the generic kernel's per-rank vectors + all_gather_object of totals / SHA-256"}
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(synth, sites_path, args.cpu_sample_reads)
             main_kind = "reference" if "reference" in cb else ("port" if "port" in cb else None)

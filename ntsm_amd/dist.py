@@ -3,6 +3,8 @@ one SUM all-reduce of the dense per-k-mer count vector + 4 totals at the end (RC
 backend is "nccl").  SUM, not MAX: per-site maxima are taken afterwards from the summed per-k-mer
 counts, which is what one reference run over all reads computes (src/FingerPrint.hpp:281-294);
 ntsmEval's merge sums maxima instead (src/CompareCounts.hpp:646-657) and is not equal to a single run."""
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -15,9 +17,11 @@ def shard_range(n_items, rank, world):
 
 
 def allreduce_sum_(vec, group=None):
-    """In-place SUM over ranks of an int64 vector (uint64 counts reinterpreted: wrap-around is identical)."""
+    """In-place SUM over ranks of an int64 vector (uint64 counts reinterpreted: wrap-around is identical).  With a process
+    group initialised the collective is issued whatever the world size: one rank summing with itself is still a real
+    RCCL call (bench.py's NTSM_FORCE_DIST leg relies on that)."""
     assert vec.dtype == torch.int64
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
     return vec
 
@@ -29,13 +33,23 @@ class _DeviceVector:
         self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
 
-def merge_counts(ctx, group=None):
-    """Job-wide counts/totals on every rank: gather dense counts on the device, all-reduce, import."""
+def merge_counts(ctx, group=None, times=None):
+    """Job-wide counts/totals on every rank: gather dense counts on the device, all-reduce, import.
+    `times` (optional list of three floats) accumulates host seconds of the three parts: [0] waiting for this rank's own
+    count kernels + the dense gather, [1] the all-reduce until it has completed on the device, [2] the import."""
+    t0 = time.perf_counter()
     ptr, n_words = ctx.counts_device()
+    t1 = time.perf_counter()
     vec = torch.as_tensor(_DeviceVector(ptr, n_words), device="cuda")
     allreduce_sum_(vec, group)
     torch.cuda.synchronize()
+    t2 = time.perf_counter()
     ctx.import_reduced()
+    if times is not None:
+        times[0] += t1 - t0
+        times[1] += t2 - t1
+        times[2] += time.perf_counter() - t2
+    return n_words
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -627,6 +627,28 @@ def test_bench_two_ranks_over_rccl(nt):
     line = json.loads([l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert "RCCL SUM" in line["config"]["parallelism"]
+    _assert_dist_line_is_self_checking(line, 2)
+
+
+def _assert_dist_line_is_self_checking(line, world):
+    """The N > 1 line proves that `world` ranks merged: every rank compared its own shard with the generic kernel, the
+    RCCL-merged vector equals a host-side (gloo) sum of the ranks' generic-kernel vectors, and the collective's own view of
+    the job (ranks, payload, time) rides on the line."""
+    c, col, pr = line["check"], line["collective"], line["per_rank"]
+    assert c["equals_generic_kernel_sum_of_pieces_below_2GiB"] is True
+    assert c["every_rank_equals_generic_kernel_on_its_own_shard"] is True
+    assert c["merged_equals_host_side_gloo_sum_of_all_ranks_generic_counts"] is True and c["ranks_checked"] == world
+    assert col["ranks_seen"] == world and col["backend"] == "nccl" and col["allreduce_ms_per_step"] > 0
+    import re
+    n_kmers = int(re.search(r"(\d+) distinct 19-mers", line["config"]["workload"]).group(1))
+    assert col["payload_bytes"] == 8 * (n_kmers + 4) and n_kmers > 1_000_000   # uint64[n_kmers + 4] of the hs_n10_like set
+    assert len(pr) == world and [r["rank"] for r in pr] == list(range(world))
+    assert c["merged_total_kmers_per_step"] == sum(r["kmers_per_step"] for r in pr)
+    assert c["merged_total_hits_per_step"] == sum(r["hits_per_step"] for r in pr)
+    assert c["merged_reads_per_step"] == world * line["config"]["reads_per_gpu"]
+    assert len({r["counts_sha256"] for r in pr}) == world                  # different shards, different vectors
+    r = line["roofline"]
+    assert abs(r["avg_launch_ms"] - max(x["avg_launch_ms"] for x in pr)) < 1e-9 and (r["per_gpu"] is (world > 1))
 
 
 def test_bench_gpus_flag_launches_or_refuses(nt):
@@ -643,6 +665,7 @@ def test_bench_gpus_flag_launches_or_refuses(nt):
         assert p.returncode == 0, p.stderr.decode()[-2000:]
         line = json.loads(out[-1])
         assert len(out) == 1 and line["n_gpus"] == 2 and "self-spawned" in line["config"]["launched_by"]
+        _assert_dist_line_is_self_checking(line, 2)
     # a launcher whose world size differs from --gpus is refused as well
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "2e6"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
@@ -665,7 +688,10 @@ def test_bench_rccl_path_on_one_rank(nt):
     e = json.loads([l for l in q.stdout.decode().split("\n") if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["check"]["total_kmers_per_step"] == e["check"]["total_kmers_per_step"] and d["check"]["total_hits_per_step"] == e["check"]["total_hits_per_step"]
-    assert e["check"]["equals_generic_kernel_sum_of_pieces_below_2GiB"] is True
+    assert e["check"]["equals_generic_kernel_sum_of_pieces_below_2GiB"] is True and "collective" not in e
+    # the dist path is self-checking too: own shard against the generic kernel, the RCCL merge against a gloo host sum
+    _assert_dist_line_is_self_checking(d, 1)
+    assert d["check"]["merged_total_kmers_per_step"] == e["check"]["total_kmers_per_step"]
 
 
 def test_early_stop_across_chunks(nt, n10):
