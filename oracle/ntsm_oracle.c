@@ -446,20 +446,27 @@ void ntsm_oracle_fp_destroy(ntsm_oracle_fp *fp)
 	free(fp);
 }
 
-/* src/FingerPrint.hpp:89-103 */
-void ntsm_oracle_fp_insert_count(ntsm_oracle_fp *fp, const char *seq, uint64_t len)
+/* src/FingerPrint.hpp:89-103 with its third parameter (`unsigned multiplier = 1`, :89): a hit adds `multiplier` to the
+ * k-mer's 64-bit count and to m_totalCounts (:94-97); m_totalKmers and m_totalBases do not see it (:98-102) */
+void ntsm_oracle_fp_insert_count_mult(ntsm_oracle_fp *fp, const char *seq, uint64_t len, unsigned multiplier)
 {
 	ntsm_oracle_iter it;
 	ntsm_oracle_iter_init(&it, seq, len, fp->k);
 	while (ntsm_oracle_iter_next(&it)) {
 		rh_bucket *b = rh_find(&fp->counts, it.hv);
 		if (b) {
-			b->val += 1;
-			fp->total_hits += 1;
+			b->val += multiplier;
+			fp->total_hits += multiplier;
 		}
 		fp->total_kmers++;
 	}
 	fp->total_bases += len;
+}
+
+/* src/FingerPrint.hpp:89-103, multiplier = 1 (every call the reference itself makes) */
+void ntsm_oracle_fp_insert_count(ntsm_oracle_fp *fp, const char *seq, uint64_t len)
+{
+	ntsm_oracle_fp_insert_count_mult(fp, seq, len, 1u);
 }
 
 /* src/FingerPrint.hpp:473-488: the -m check runs after each whole read, strict '>' */

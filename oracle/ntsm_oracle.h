@@ -77,6 +77,8 @@ void ntsm_oracle_fp_destroy(ntsm_oracle_fp *fp);
 
 /* insertCount(), src/FingerPrint.hpp:89-103 (multiplier = 1) */
 void ntsm_oracle_fp_insert_count(ntsm_oracle_fp *fp, const char *seq, uint64_t len);
+/* the same with the reference's `unsigned multiplier` parameter (:89): used to reach counts >= 2^32 on small inputs */
+void ntsm_oracle_fp_insert_count_mult(ntsm_oracle_fp *fp, const char *seq, uint64_t len, unsigned multiplier);
 /* processSingleRead(), src/FingerPrint.hpp:473-488.  Returns 1 once the -m threshold tripped. */
 int ntsm_oracle_fp_process_read(ntsm_oracle_fp *fp, const char *seq, uint64_t len);
 /* computeCounts(), src/FingerPrint.hpp:46-87, serial in argv order (the single-thread schedule).

@@ -6,6 +6,9 @@
  *   ntsm_oracle -s sites.fa [-k K] [-m M] [-t T] [-d] [-o summary] [-v] reads...
  * stdout = counts.txt, stderr = warnings + summary.  `--time-scan` additionally prints
  * "SCAN_SECONDS <s> BASES <n>" for bench.py's cpu_baseline leg (site-table build excluded).
+ * `--insert-multiplier M` replaces computeCounts by "every record through insertCount(seq, len, M)" -- the reference's
+ * own third parameter (src/FingerPrint.hpp:89) -- exactly like oracle/ref_driver.cpp under NTSM_REF_INSERT_MULTIPLIER:
+ * the way to per-k-mer counts beyond 2^32 on a small input (tests/golden/make_wrap.py, printCountsMax's `unsigned`).
  */
 #define _POSIX_C_SOURCE 200809L
 #include "ntsm_oracle.h"
@@ -26,7 +29,8 @@ int main(int argc, char **argv)
 	const char *sites = NULL, *summary = NULL;
 	unsigned k = 19;                              /* Options.h:24 */
 	double cov = DBL_MAX;                         /* Options.h:32 */
-	int dupes = 0, time_scan = 0, n_files = 0;
+	int dupes = 0, time_scan = 0, n_files = 0, use_mult = 0;
+	unsigned mult = 1;
 	const char **files = (const char **) calloc((size_t) argc, sizeof(char *));
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "-s") && i + 1 < argc) sites = argv[++i];
@@ -37,6 +41,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "-d")) dupes = 1;
 		else if (!strcmp(argv[i], "-v")) { }
 		else if (!strcmp(argv[i], "--time-scan")) time_scan = 1;
+		else if (!strcmp(argv[i], "--insert-multiplier") && i + 1 < argc) { use_mult = 1; mult = (unsigned) strtoul(argv[++i], NULL, 10); }
 		else files[n_files++] = argv[i];
 	}
 	if (!sites || n_files == 0) {
@@ -46,7 +51,15 @@ int main(int argc, char **argv)
 	ntsm_oracle_fp *fp = ntsm_oracle_fp_create(sites, k, cov, dupes, stderr);
 	if (!fp) return 1;
 	double t0 = now_s();
-	if (ntsm_oracle_fp_compute_counts(fp, files, n_files, stderr)) return 1;
+	if (use_mult) {
+		for (int i = 0; i < n_files; ++i) {
+			ntsm_oracle_reader *r = ntsm_oracle_reader_open(files[i]);
+			if (!r) { fprintf(stderr, "file %s cannot be opened\n", files[i]); return 1; }
+			for (int64_t l = ntsm_oracle_reader_next(r); l >= 0; l = ntsm_oracle_reader_next(r))
+				ntsm_oracle_fp_insert_count_mult(fp, ntsm_oracle_reader_seq(r), (uint64_t) l, mult);
+			ntsm_oracle_reader_close(r);
+		}
+	} else if (ntsm_oracle_fp_compute_counts(fp, files, n_files, stderr)) return 1;
 	double t1 = now_s();
 	if (ntsm_oracle_fp_print_counts(fp, stdout) != 0) {
 		fflush(stdout);

@@ -19,6 +19,11 @@
  *   -s FILE  -k INT  -m FLOAT  -t INT  -d  -o FILE  -v      (same meaning as
  *   src/ntSeqMatchCount.cpp:75-136).  Output goes to stdout/stderr exactly like the reference.
  * With NTSM_REF_TIME_SCAN set, the wall time of computeCounts() alone is also printed ("SCAN_SECONDS x").
+ * With NTSM_REF_INSERT_MULTIPLIER=M set, computeCounts() is replaced by its own loop written out here -- gzopen, kseq_read,
+ * one call of the reference's public FingerPrint::insertCount(seq, len, M) per record (src/FingerPrint.hpp:89, its third
+ * parameter) -- so that per-k-mer counts reach and pass 2^32 on a small input: the only way to see what the reference's
+ * printCountsMax() does with such counts (`unsigned`, :282/:289) without feeding it four billion reads
+ * (tests/golden/make_wrap.py).
  */
 #include <cassert>
 #include <cstdlib>
@@ -55,7 +60,18 @@ int main(int argc, char **argv)
 	double time = omp_get_wtime();
 	FingerPrint fp;                                             /* :177 */
 	const double scan0 = omp_get_wtime();
-	fp.computeCounts(files);                                    /* :178 */
+	if (const char *mul = getenv("NTSM_REF_INSERT_MULTIPLIER")) {
+		const unsigned m = (unsigned) strtoul(mul, nullptr, 10);
+		for (const std::string &f : files) {                    /* the loop of computeCounts (:49-69) around insertCount(.., m) */
+			gzFile fh = gzopen(f.c_str(), "r");
+			if (fh == Z_NULL) { std::cerr << "file " << f << " cannot be opened" << std::endl; return 1; }
+			kseq_t *seq = kseq_init(fh);
+			while (kseq_read(seq) >= 0) fp.insertCount(seq->seq.s, seq->seq.l, m);
+			kseq_destroy(seq);
+			gzclose(fh);
+		}
+	} else
+		fp.computeCounts(files);                                /* :178 */
 	if (getenv("NTSM_REF_TIME_SCAN"))                           /* bench.py cpu_baseline: the scan alone, site-table build excluded */
 		std::cerr << "SCAN_SECONDS " << omp_get_wtime() - scan0 << std::endl;
 	fp.printOptionalHeader();                                   /* :179 */

@@ -48,6 +48,11 @@ def lib():
         L.ntsm_oracle_fp_early_term.argtypes = [C.c_void_p]
         L.ntsm_oracle_fp_kmers.restype = C.c_uint64
         L.ntsm_oracle_fp_kmers.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_uint64]
+        L.ntsm_oracle_fp_insert_count_mult.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint]
+        L.ntsm_oracle_fp_print_counts.restype = C.c_int
+        L.ntsm_oracle_fp_print_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.ntsm_oracle_fp_info_summary.restype = C.c_int
+        L.ntsm_oracle_fp_info_summary.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -79,6 +84,30 @@ class OracleFP:
     def process(self, seq):
         """processSingleRead; returns True once the -m threshold tripped."""
         return bool(self.L.ntsm_oracle_fp_process_read(self.h, seq, len(seq)))
+
+    def insert_mult(self, seq, multiplier):
+        """insertCount(seq, len, multiplier), src/FingerPrint.hpp:89 (the reference's own third parameter)."""
+        assert 0 <= multiplier < 2 ** 32
+        self.L.ntsm_oracle_fp_insert_count_mult(self.h, seq, len(seq), multiplier)
+
+    def print_counts(self):
+        """(rc, bytes) of printOptionalHeader() + printCountsMax(), src/FingerPrint.hpp:261-311."""
+        import tempfile
+        libc = C.CDLL(None)
+        libc.fdopen.restype = C.c_void_p
+        libc.fdopen.argtypes = [C.c_int, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        with tempfile.TemporaryFile() as f:
+            fh = libc.fdopen(os.dup(f.fileno()), b"w")
+            rc = self.L.ntsm_oracle_fp_print_counts(self.h, fh)
+            libc.fclose(fh)
+            f.seek(0)
+            return rc, f.read()
+
+    def info_summary(self):
+        buf = C.create_string_buffer(2048)
+        n = self.L.ntsm_oracle_fp_info_summary(self.h, buf, 2048, None)
+        return buf.raw[:n]
 
     def process_flat(self, bases, read_end):
         """Feed a flat stream read by read, stopping like computeCounts does."""

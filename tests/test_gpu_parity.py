@@ -19,6 +19,7 @@ G = os.path.join(ROOT, "tests", "golden")
 GOLD = json.load(open(os.path.join(G, "cases.json")))
 CASES = GOLD["cases"]
 OK_CASES = [c for c in CASES if c["rc"] == 0]
+HOT_KEY_MAX_FACTOR = 4.0          # test_hot_key_throughput_guard: slowdown allowed when every hit lands on the same few counters
 
 
 @pytest.fixture(scope="module")
@@ -1232,3 +1233,116 @@ def test_bench_contract_line(nt):
     assert o["long"]["m10"]["early_stop"] in (True, False) and o["long"]["m10"]["stop_read"] <= o["long"]["reads"]
     assert o["stress"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["stress"]["gbases_per_s"] > 0
     assert o["e2e_cli"]["check"]["counts_txt_equals_resident_path"] and o["e2e_cli"]["wall_s"] > 0 and len(o["e2e_cli"]["counts_sha256"]) == 64
+
+
+def test_counts_at_and_beyond_2_32_print_like_the_reference(nt):
+    """the table's counters are 64 bits wide (m_counts' size_t, src/FingerPrint.hpp:466) but printCountsMax
+    passes them through `unsigned` (:282, :289).  (a) The recorded reference outputs of tests/golden/make_wrap.py, whose
+    counts were pushed past 2^32 by the reference's own insertCount multiplier: the same 64-bit vector handed to a GPU
+    context as a merged result (ntsm_import_reduced, the route an all-reduce takes) comes back intact through ntsm_counts /
+    ntsm_sync and prints the reference's bytes.  (b) Counters that really get there on the device: a stream of one site
+    k-mer, counted until the k-mer's counter has passed 2^32 -- exact 64-bit value from the atomics, truncated value in
+    the printed row, equal to the oracle's printer on the same count."""
+    import torch
+    from ntsm_amd.dist import _DeviceVector
+    from oracle_binding import read_records
+    inp = os.path.join(G, "inputs")
+    for case in json.load(open(os.path.join(G, "wrap.json")))["cases"]:
+        exp = open(os.path.join(G, "expected", case["stdout"]), "rb").read()
+        fp = OracleFP(os.path.join(inp, case["sites"]))
+        for f in case["files"]:
+            for _, seq in read_records(os.path.join(inp, f))[0]:
+                fp.insert_mult(seq, case["multiplier"])
+        _, _, cnt = fp.kmers()
+        sites = nt.Sites(os.path.join(inp, case["sites"]))
+        ctx = nt.Context(sites.keys)
+        ptr, words = ctx.counts_device()
+        vec = torch.as_tensor(_DeviceVector(ptr, words), device="cuda")
+        tail = np.array([fp.total_kmers, fp.total_hits, fp.total_bases, 2003], dtype=np.uint64)
+        vec.copy_(torch.from_numpy(np.concatenate([cnt, tail]).view(np.int64)))
+        torch.cuda.synchronize()
+        ctx.import_reduced()
+        t = ctx.sync()
+        got = ctx.counts()
+        assert np.array_equal(got, cnt) and int(got.max()) >= 2 ** 32
+        assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases) and t.total_hits >= 2 ** 32
+        assert sites.format_counts(got, t.total_kmers) == (0, exp)
+        ctx.close()
+    # (b) real atomics past 2^32 on one counter
+    path = os.path.join(inp, "sites200.fa")
+    sites = nt.Sites(path)
+    fp = OracleFP(path)
+    canon, _, _ = fp.kmers()
+    first = open(path).read().split("\n")[1].split("N")[0]            # first k-mer of the first record
+    assert len(first) == 19
+    n_reads = 50_000_000                                               # 1 GB of stream: "<19-mer>N" x 5e7
+    unit = torch.from_numpy(np.frombuffer((first + "N").encode() * 4, dtype=np.uint8).copy()).cuda()    # 80 bytes = 4 reads, 16-byte multiple
+    d_bases = unit.repeat(n_reads // 4)
+    torch.cuda.synchronize()
+    ctx = nt.Context(sites.keys)
+    passes = 2 ** 32 // n_reads + 2                                    # 87 passes: 4.35e9 > 2^32
+    for _ in range(passes):
+        ctx.count_resident(d_bases.data_ptr(), d_bases.numel(), 0, n_reads)
+    t = ctx.sync()
+    got = ctx.counts()
+    total = passes * n_reads
+    assert total > 2 ** 32 and (t.total_kmers, t.total_hits, t.total_bases) == (total, total, 19 * total)
+    assert int(got[0]) == total and int(got.sum()) == total            # one counter took every hit, 64 bits wide
+    fp.insert_mult(first.encode(), 4_000_000_000)
+    fp.insert_mult(first.encode(), total - 4_000_000_000)
+    assert np.array_equal(fp.kmers()[2], got)
+    rc, text = sites.format_counts(got, t.total_kmers)
+    assert (rc, text) == fp.print_counts()
+    row = text.split(b"\n")[3].split(b"\t")
+    assert int(row[1]) == total - 2 ** 32 and int(row[3]) == total - 2 ** 32       # truncated maximum and sum of rs0's first allele
+    ctx.close()
+
+
+def test_hot_key_throughput_guard(nt, n10):
+    """Every hit bumps its counter with one 64-bit atomic (ntsm_hip.hip, drain stage 3).  On ordinary reads 0.5 % of the
+    windows hit and the hits spread over 1.5 M counters; a low-complexity input can put them all on a handful.  1e7 reads
+    that are all the same 31-base site window (13 hits per read on at most 13 counters): the counts must be exact and the
+    pass must stay within the stated factor of the ordinary rate."""
+    import torch
+    s, sites, path = n10
+    n = 10_000_000
+    dev = torch.device("cuda:0")
+    d_win = torch.from_numpy(s.windows).to(dev)
+    d_ord = torch.empty(n * s.stride, dtype=torch.uint8, device=dev)
+    s.device_fill(d_win.data_ptr(), 0, n, d_ord.data_ptr())
+    # the hot stream: one read's layout (150 bases + 'N' + pad to the stride), its bases = filler + the first site's REF window
+    rng = np.random.default_rng(5)
+    window = "".join("ACGT"[c] for c in s.windows[:31])    # the first site's REF window (32-byte records of 2-bit codes, 31 bases)
+    filler = "".join("ACGT"[i] for i in rng.integers(0, 4, 150 - len(window)))
+    read = (filler[:60] + window + filler[60:]).encode()
+    assert len(read) == 150
+    one = np.full(s.stride, ord("N"), dtype=np.uint8)
+    one[:150] = np.frombuffer(read, dtype=np.uint8)
+    reps = 16 // np.gcd(16, s.stride)
+    d_hot = torch.from_numpy(np.tile(one, reps)).to(dev).repeat(n // reps)
+    assert d_hot.numel() == n * s.stride
+    torch.cuda.synchronize()
+    fp = OracleFP(path)
+    fp.process(read)
+    hits_per_read = fp.total_hits
+    assert hits_per_read >= 1
+    _, _, per = fp.kmers()
+    ms = {}
+    for name, buf in (("ordinary", d_ord), ("hot", d_hot)):
+        ctx = nt.Context(sites.keys)
+        ctx.count_resident(buf.data_ptr(), buf.numel(), 0, n)
+        ctx.sync()
+        ctx.reset()
+        ctx.set_timing(True)
+        for _ in range(3):
+            ctx.count_resident(buf.data_ptr(), buf.numel(), 0, n)
+        t = ctx.sync()
+        k, total_ms = ctx.get_timing()
+        ms[name] = total_ms / k
+        if name == "hot":
+            assert t.total_hits == 3 * n * hits_per_read and t.total_kmers == 3 * n * fp.total_kmers
+            assert np.array_equal(ctx.counts(), per * np.uint64(3 * n))
+        ctx.close()
+    factor = ms["hot"] / ms["ordinary"]
+    print("hot-key pass %.2f ms, ordinary pass %.2f ms, factor %.2f, %d hits per read" % (ms["hot"], ms["ordinary"], factor, hits_per_read))
+    assert factor < HOT_KEY_MAX_FACTOR, (ms, factor)
