@@ -20,6 +20,11 @@ extern "C" {
  * Returns 0 or a negative error. */
 int ntsm_synth_sites(uint64_t seed, uint32_t n_sites, unsigned k, uint8_t *windows,
 		const char *fasta_path, uint64_t *n_kmers);
+/* The same with the smallest number of k-mer start positions a site keeps (0 = the default 3; 13 at k = 19 keeps every
+ * k-mer of every window: 96287 sites -> 2,503,462 site k-mers, the upper bound SURVEY.md section 8a gives for the real
+ * human_sites_n10.fa -- bench.py's n10_full leg).  The draws of a site do not depend on this value beyond the count kept. */
+int ntsm_synth_sites_keep(uint64_t seed, uint32_t n_sites, unsigned k, unsigned min_keep, uint8_t *windows,
+		const char *fasta_path, uint64_t *n_kmers);
 
 /* Fill parameter blocks from probabilities. */
 void ntsm_synth_short_params(ntsm_synth_short *p, uint64_t seed, uint32_t read_len, uint32_t n_sites,

@@ -110,6 +110,7 @@ _sig(HO, "ntsm_host_format_summary", C.c_int, [C.c_void_p, u64p, C.c_uint64, C.c
 
 SY = synth_lib
 _sig(SY, "ntsm_synth_sites", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint, u8p, C.c_char_p, u64p])
+_sig(SY, "ntsm_synth_sites_keep", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint, C.c_uint, u8p, C.c_char_p, u64p])
 _sig(SY, "ntsm_synth_short_params", None, [C.POINTER(SynthShortParams), C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_double, C.c_double, C.c_double])
 _sig(SY, "ntsm_synth_long_params", None, [C.POINTER(SynthLongParams), C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_double])
@@ -396,12 +397,13 @@ class SynthShort:
     """Seeded short-read workload (ntsm_amd/csrc/synth.h); sites + reads share one object."""
 
     def __init__(self, sites_seed, n_sites, k=19, read_seed=7, read_len=150, p_embed=0.10, p_sub=0.01, p_n=5e-4,
-                 sites_path=None):
+                 sites_path=None, min_keep=0):
+        """min_keep: smallest number of k-mer start positions a site keeps (0 = 3 .. 13 uniformly; 13 = every k-mer)."""
         self.n_sites, self.k, self.read_len = n_sites, k, read_len
         self.windows = np.zeros(n_sites * 2 * 32, dtype=np.uint8)
         nk = C.c_uint64()
-        rc = SY.ntsm_synth_sites(sites_seed, n_sites, k, _p(self.windows, u8p),
-                                 os.fsencode(sites_path) if sites_path else None, C.byref(nk))
+        rc = SY.ntsm_synth_sites_keep(sites_seed, n_sites, k, min_keep, _p(self.windows, u8p),
+                                      os.fsencode(sites_path) if sites_path else None, C.byref(nk))
         if rc:
             raise NtsmError("ntsm_synth_sites failed: %d" % rc)
         self.n_kmers = int(nk.value)

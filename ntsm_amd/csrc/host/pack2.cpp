@@ -1,7 +1,12 @@
 #include "pack2.hpp"
 
 #include <cstring>
+#if defined(__x86_64__) || defined(__i386__)
+#define NTSM_PACK2_X86 1
 #include <immintrin.h>
+#else
+#define NTSM_PACK2_X86 0                 /* other hosts: the portable loop only */
+#endif
 
 namespace ntsm {
 
@@ -38,6 +43,7 @@ inline void group_scalar(uint8_t *codes8, uint8_t *valid4, const uint8_t *b, uns
 	memcpy(valid4, &v, 4);
 }
 
+#if NTSM_PACK2_X86
 __attribute__((target("avx2"))) inline void group_avx2(uint8_t *codes8, uint8_t *valid4, const uint8_t *b, unsigned n)
 {
 	const __m256i x = _mm256_loadu_si256((const __m256i *) b);
@@ -72,12 +78,17 @@ __attribute__((target("avx2"))) inline void group_avx2(uint8_t *codes8, uint8_t 
 	memcpy(codes8, &packed, 8);
 	memcpy(valid4, &v, 4);
 }
+#endif
 
 bool g_force_scalar = false;
 bool has_avx2()
 {
+#if NTSM_PACK2_X86
 	static const bool yes = __builtin_cpu_supports("avx2");
 	return yes;
+#else
+	return false;
+#endif
 }
 
 /* groups of 32 positions starting at pos (a multiple of 8: codes byte pos / 4, valid byte pos / 8); the last group holds the
@@ -92,10 +103,12 @@ bool has_avx2()
 	GROUP(codes + ((pos + i) >> 2), valid + ((pos + i) >> 3), tail, n);                         \
 	return (pos + len + 8) & ~7ull;
 
+#if NTSM_PACK2_X86
 __attribute__((target("avx2"))) uint64_t append_avx2(uint8_t *codes, uint8_t *valid, uint64_t pos, const uint8_t *s, uint64_t len)
 {
 	NTSM_PACK2_BODY(group_avx2)
 }
+#endif
 
 uint64_t append_scalar(uint8_t *codes, uint8_t *valid, uint64_t pos, const uint8_t *s, uint64_t len)
 {
@@ -107,7 +120,9 @@ uint64_t append_scalar(uint8_t *codes, uint8_t *valid, uint64_t pos, const uint8
 
 uint64_t pack2_append(uint8_t *codes, uint8_t *valid, uint64_t pos, const char *seq, uint64_t len)
 {
+#if NTSM_PACK2_X86
 	if (!g_force_scalar && has_avx2()) return append_avx2(codes, valid, pos, (const uint8_t *) seq, len);
+#endif
 	return append_scalar(codes, valid, pos, (const uint8_t *) seq, len);
 }
 

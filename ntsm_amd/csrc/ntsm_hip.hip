@@ -978,6 +978,8 @@ struct ntsm_ctx {
 	/* host-side totals */
 	uint64_t total_bases = 0, reads_consumed = 0;
 	bool early_stop = false, reduced = false;
+	bool failed = false;                       /* a table rebuild failed half way (ntsm_set_kernel / ntsm_set_tuning): the tables no longer
+	                                            * describe one consistent filter organisation; every later call answers NTSM_ERR_STATE */
 	uint64_t red_totals[4] = { 0, 0, 0, 0 };
 	/* tuning / timing */
 	int grid_blocks = 0, n_cu = 256;
@@ -1114,10 +1116,17 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 				 * 13.5 bits per key in steps of 64 KiB, at most 3 MiB: the filter shares the 4 MiB L2 with the stream and the
 				 * look-ups' lines, and past ~2.75 MiB every further bit per key is paid for in L2 misses.  Measured on the bench
 				 * set (1.54 M keys, 3e8 reads; 2 / 2.25 / 2.375 / 2.5 / 2.625 / 2.75 / 3 MiB): 862 / 883 / 888 / 891 / 888 / 885 /
-				 * 863 Gbases/s; 2.08 M keys: 3 MiB 777, 3.25 770; 2.56 M keys: 3 / 3.25 / 3.5 / 3.75 / 4 MiB: 718 / 721 / 722 / 711 / 716. */
-				const uint64_t kib = std::min<uint64_t>(3072, std::max<uint64_t>(1, (27ull * n / 16 + 1023) / 1024));   /* 13.5 bits = 27/16 bytes per key */
-				c->n_blocks = std::max<uint64_t>(16, ((kib + 63) / 64 * 64) * 64);
-				if (kib < 64) c->n_blocks = std::max<uint64_t>(16, kib * 64);
+				 * 863 Gbases/s; 2.08 M keys: 3 MiB 777, 3.25 770; 2.56 M keys: 3 / 3.25 / 3.5 / 3.75 / 4 MiB: 718 / 721 / 722 / 711 / 716.
+				 * The cap only makes sense where a bigger set has somewhere else to go: k = 13, 14 have no 14-mer minimizers and a
+				 * context forced to one level (ntsm_set_kernel 2) must not fall back on a saturated 3 MiB filter -- those keep the
+				 * 2^e / 3 * 2^(e-2) ladder at >= 12 bits per key computed above (up to 64 MiB). */
+				const bool has_two_level_form = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 2;
+				const uint64_t kib_want = std::max<uint64_t>(1, (27ull * n / 16 + 1023) / 1024);   /* 13.5 bits = 27/16 bytes per key */
+				if (has_two_level_form || kib_want <= 3072) {
+					const uint64_t kib = std::min<uint64_t>(3072, kib_want);
+					c->n_blocks = std::max<uint64_t>(16, ((kib + 63) / 64 * 64) * 64);
+					if (kib < 64) c->n_blocks = std::max<uint64_t>(16, kib * 64);
+				}
 			}
 			if (c->blocks_kib_req) c->n_blocks = (uint64_t) c->blocks_kib_req * 64;   /* tuning: any size, the index is a multiply-high range reduction */
 			c->blk_map.n_blocks = (uint32_t) c->n_blocks;
@@ -2155,6 +2164,7 @@ int ntsm_count_resident(ntsm_ctx *c, const void *d_bases, uint64_t n_bytes, cons
 {
 	if (!c || (n_bytes && !d_bases) || (sign != 1 && sign != -1)) return NTSM_ERR_ARG;
 	if (((uintptr_t) d_bases & 15) != 0) return NTSM_ERR_ARG;
+	if (c->failed) return NTSM_ERR_STATE;
 	if (n_reads == 0 || n_bytes == 0) return NTSM_OK;
 	if (c->early_stop) return NTSM_OK;
 	c->reduced = false;
@@ -2173,6 +2183,7 @@ int ntsm_count_resident(ntsm_ctx *c, const void *d_bases, uint64_t n_bytes, cons
 int ntsm_sync(ntsm_ctx *c, ntsm_totals *t)
 {
 	if (!c) return NTSM_ERR_ARG;
+	if (c->failed) return NTSM_ERR_STATE;
 	{
 		std::lock_guard<std::mutex> lk(c->mu);
 		if (c->open_lanes) return NTSM_ERR_STATE;             /* lanes hold batches this call cannot see: close them first */
@@ -2332,7 +2343,7 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 		filter_log2_bits = c->filter_log2_req;
 		HIPCHK(hipSetDevice(c->device));
 		rc = build_tables(c, filter_log2_bits);
-		if (rc) return rc;
+		if (rc) { c->failed = true; return rc; }          /* old tables freed, new ones incomplete: the context is unusable */
 		HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
 		HIPCHK(hipDeviceSynchronize());
 		c->total_bases = c->reads_consumed = 0;
@@ -2342,7 +2353,7 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 	if (filter_log2_bits > 0) {
 		c->filter_log2_req = filter_log2_bits;
 		rc = build_tables(c, filter_log2_bits);              /* rebuilds filters and table: counts start from zero again */
-		if (rc) return rc;
+		if (rc) { c->failed = true; return rc; }
 		HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
 		HIPCHK(hipDeviceSynchronize());
 		c->total_bases = c->reads_consumed = 0;
@@ -2374,12 +2385,15 @@ int ntsm_set_kernel(ntsm_ctx *c, int variant)
 	const int before = c->kernel_variant;
 	c->kernel_variant = variant;
 	/* one-level and two-level filters are different tables (12-mer / 14-mer minimizers): a change of level rebuilds them */
+	/* (the tabulated kernel hands its exotic tiles to the ONE-level k = 19 kernel: variant 3 on a context that had chosen two
+	 * levels by itself rebuilds the one-level tables, otherwise those tiles would probe 14-mer-addressed blocks with 12-mers) */
 	const bool want_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && variant != 1 && variant != 3 &&
 		(variant == 4 || (variant == 0 && c->filter_log2_req == 0 && ntsm_wants_two_level(c->n_kmers)));
-	if (variant != 1 && variant != 3 && want_two != c->two_level) {
+	(void) before;
+	if (variant != 1 && want_two != c->two_level) {
 		HIPCHK(hipSetDevice(c->device));
 		rc = build_tables(c, c->filter_log2_req);
-		if (rc) { c->kernel_variant = before; return rc; }
+		if (rc) { c->failed = true; return rc; }            /* old tables freed, new ones incomplete: the context is unusable */
 		HIPCHK(hipMemset(c->d_totals, 0, 4 * sizeof(uint64_t)));
 		HIPCHK(hipDeviceSynchronize());
 		c->total_bases = c->reads_consumed = 0;

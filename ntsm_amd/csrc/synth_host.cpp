@@ -85,9 +85,15 @@ extern "C" {
 int ntsm_synth_sites(uint64_t seed, uint32_t n_sites, unsigned k, uint8_t *windows,
 		const char *fasta_path, uint64_t *n_kmers_out)
 {
+	return ntsm_synth_sites_keep(seed, n_sites, k, 0, windows, fasta_path, n_kmers_out);
+}
+
+int ntsm_synth_sites_keep(uint64_t seed, uint32_t n_sites, unsigned k, unsigned min_keep_req, uint8_t *windows,
+		const char *fasta_path, uint64_t *n_kmers_out)
+{
 	if (k == 0 || k > 31 || k > NTSM_SYNTH_W) return -1;
 	const unsigned n_starts = NTSM_SYNTH_W - k + 1;          /* 13 for k = 19 */
-	const unsigned min_keep = n_starts < 3 ? n_starts : 3;
+	const unsigned min_keep = min_keep_req ? (min_keep_req < n_starts ? min_keep_req : n_starts) : (n_starts < 3 ? n_starts : 3);
 	Out out;
 	if (fasta_path && !out.open(fasta_path)) return -2;
 	CodeSet seen((uint64_t) n_sites * 2 * n_starts);

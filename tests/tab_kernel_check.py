@@ -3,7 +3,9 @@ tests/test_gpu_parity.py::test_tabulated_kernel_paths as a subprocess with NTSM_
 Inputs that take its special paths: (a) reads made of site sequence -- far more windows pass the filter than a wave's
 queue slot holds, so they are looked up in line; (b) a clean stream with a few foreign bytes -- only the tiles that hold
 them go to the exact kernel; (c) lowercase / U / N-rich input stays on the tabulated kernel; (d) several launches reuse
-the per-stream buffers; (e) the filter sizes its block map treats differently, against the default kernel's counts."""
+the per-stream buffers; (e) the filter sizes its block map treats differently, against the default kernel's counts;
+(f) a site set big enough to choose the two-level tables by itself: variant 3 hands its exotic tiles to
+the ONE-level k = 19 kernel, so ntsm_set_kernel(ctx, 3) must rebuild the one-level tables first."""
 import os
 import sys
 
@@ -69,5 +71,34 @@ for flog in (0, 20, 25, 124):
     ctx.submit(bases, ends)
     t = ctx.sync()
     assert np.array_equal(ctx.counts(), cr) and (t.total_kmers, t.total_hits) == (tr.total_kmers, tr.total_hits), flog
+    ctx.close()
+
+# (f) 250,000 sites = 4 M site k-mers: beyond the automatic switch to two levels (3.1 M)
+import tempfile
+with tempfile.TemporaryDirectory() as d:
+    bp = os.path.join(d, "big.fa")
+    sb = nt.SynthShort(sites_seed=777, n_sites=250_000, read_seed=3, p_embed=0.3, sites_path=bp)
+    big = nt.Sites(bp)
+    assert len(big.keys) > 3_200_000
+    n = 4000
+    buf = sb.host_bytes(0, n).copy()
+    for at, b in ((900, ord("R")), (150_000, 0), (400_000, ord("-")), (590_000, ord("*"))):
+        buf[at] = b
+    e = sb.read_end(n)
+    fp = OracleFP(bp)
+    fp.process_flat(buf, e)
+    ctx = nt.Context(big.keys)
+    assert ctx.debug_stats()["two_level"] is True
+    ctx.set_kernel(3)
+    assert ctx.debug_stats()["two_level"] is False
+    ctx.submit(buf, e)
+    t = ctx.sync()
+    st = ctx.debug_stats()
+    assert np.array_equal(ctx.counts(), fp.kmers()[2]) and (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits)
+    assert st["launches_tab"] == 1 and st["exotic_tiles"] >= 3, st
+    ctx.set_kernel(0)                                    # back to automatic: two levels again, same counts
+    assert ctx.debug_stats()["two_level"] is True
+    ctx.submit(buf, e)
+    assert np.array_equal(ctx.counts(), fp.kmers()[2])
     ctx.close()
 print("ok")

@@ -2,7 +2,10 @@
 """tools/stress_sweep.py [variant:tuning ...] -- BASELINE.json configs[4] (1 M sites, 16 M k-mers) through several kernel
 forms / filter sizes in ONE process (the site set is generated once).  variant = ntsm_set_kernel code (0 auto, 2 one level,
 4 two levels), tuning = ntsm_set_tuning code (0 none; 10..30 / 100..130 block filter bits; 200..299 Bloom bits).  A second
-tuning after a comma is applied after the first (e.g. 4:126,273).  One JSON line per configuration."""
+tuning after a comma is applied after the first (e.g. 4:126,273).  One JSON line per configuration.
+Environment: NTSM_STRESS_SITES (1e6), NTSM_STRESS_READS (1e8), NTSM_STRESS_SEED (424242), NTSM_STRESS_MIN_KEEP (0 = 3..13 k-mers per
+allele; 13 = all of them: with 96287 sites and seed 20241218 that is bench.py's n10_full set of 2,503,462 k-mers),
+NTSM_STRESS_P_EMBED (0.10)."""
 import json, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +17,8 @@ tmp = tempfile.mkdtemp(prefix="ntsm_sweep_")
 sp = os.path.join(tmp, "stress.fa")
 n_sites = int(float(os.environ.get("NTSM_STRESS_SITES", 1e6)))
 n_reads = int(float(os.environ.get("NTSM_STRESS_READS", 1e8)))
-s = ntsm_amd.SynthShort(424242, n_sites, read_seed=9, sites_path=sp)
+s = ntsm_amd.SynthShort(int(os.environ.get("NTSM_STRESS_SEED", 424242)), n_sites, read_seed=9, sites_path=sp,
+                        min_keep=int(os.environ.get("NTSM_STRESS_MIN_KEEP", 0)), p_embed=float(os.environ.get("NTSM_STRESS_P_EMBED", 0.10)))
 sites = ntsm_amd.Sites(sp)
 d_win = torch.from_numpy(s.windows).to(dev)
 d_bases = torch.empty(n_reads * s.stride, dtype=torch.uint8, device=dev)
