@@ -15,7 +15,7 @@ CSRC     := ntsm_amd/csrc
 
 HOST     := $(CSRC)/host
 HOSTSRC  := $(HOST)/seq_reader.cpp $(HOST)/site_set.cpp $(HOST)/report.cpp $(HOST)/parallel_fastq.cpp \
-            $(HOST)/inflate.cpp $(HOST)/gz_stream.cpp $(HOST)/crc32_fast.cpp $(HOST)/pack2.cpp
+            $(HOST)/inflate.cpp $(HOST)/inflate_spec.cpp $(HOST)/gz_stream.cpp $(HOST)/gz_parallel.cpp $(HOST)/crc32_fast.cpp $(HOST)/pack2.cpp
 HOSTHDR  := $(wildcard $(HOST)/*.hpp) include/ntsm_host.h include/ntsm_hip.h
 
 all: oracle_all build/ntsm_synth build/gather_bench ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount ntsm_amd/libntsm_eval_hip.so build/ntsmEval

@@ -47,6 +47,12 @@ const char *ntsm_host_pack2_impl(void);
  * `chunk` bytes per call.  out / len receive the bytes delivered
  * (free with ntsm_host_free); returns the last read's result: 0 = clean end, -1 = error, -2 = cannot open. */
 int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out, uint64_t *len);
+/* Test hook: compressed bytes per chunk of the parallel decoder for plain (non-BGZF) gzip input that engine n >= 2 uses
+ * (0 = the default 2 MiB; files shorter than two chunks are decoded in order).  stats, if not NULL, receives what the last
+ * ntsm_host_gunzip call with engine >= 2 did: [0] chunks spliced in, [1] chunks dropped (no block start found in their
+ * range, start not confirmed by the in-order decoder, or decoding failed). */
+void ntsm_host_gunzip_parallel_chunk(uint64_t bytes);
+void ntsm_host_gunzip_parallel_stats(uint64_t stats[2]);
 /* Block-parallel variant for plain 4-line FASTQ (ntsm_amd/csrc/host/parallel_fastq.hpp), for tests: the records
  * the parallel phase commits (in file order) followed by what the sequential reader yields from *resume on.
  * Returns 0, 1 if the file is not eligible (callers use ntsm_host_flatten), -1 if it cannot be opened.

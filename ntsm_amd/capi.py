@@ -101,6 +101,8 @@ _sig(HO, "ntsm_host_max_hits", C.c_uint64, [C.c_uint64, C.c_double])
 _sig(HO, "ntsm_host_flatten", C.c_int, [C.c_char_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, C.POINTER(C.c_int)])
 _sig(HO, "ntsm_host_free", None, [C.c_void_p])
 _sig(HO, "ntsm_host_gunzip", C.c_int, [C.c_char_p, C.c_int, C.c_uint, C.POINTER(u8p), u64p])
+_sig(HO, "ntsm_host_gunzip_parallel_chunk", None, [C.c_uint64])
+_sig(HO, "ntsm_host_gunzip_parallel_stats", None, [u64p])
 _sig(HO, "ntsm_host_flatten_parallel", C.c_int, [C.c_char_p, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, u64p])
 _sig(HO, "ntsm_host_pack2_append", C.c_uint64, [u8p, u8p, C.c_uint64, u8p, C.c_uint64, C.c_int])
 _sig(HO, "ntsm_host_pack2_impl", C.c_char_p, [])
@@ -208,6 +210,18 @@ def gunzip(path, engine=0, chunk=1 << 16):
     data = C.string_at(b, n.value)
     HO.ntsm_host_free(b)
     return data, rc
+
+
+def gunzip_parallel_chunk(n_bytes):
+    """Compressed bytes per chunk of the parallel plain-gzip decoder (engine >= 2); 0 = default."""
+    HO.ntsm_host_gunzip_parallel_chunk(C.c_uint64(n_bytes))
+
+
+def gunzip_parallel_stats():
+    """(chunks spliced, chunks dropped) of the last gunzip(path, engine >= 2) call."""
+    st = (C.c_uint64 * 2)()
+    HO.ntsm_host_gunzip_parallel_stats(C.cast(st, u64p))
+    return int(st[0]), int(st[1])
 
 
 def flatten_file_parallel(path, n_threads=4, block_bytes=1 << 20):

@@ -11,7 +11,9 @@
 #include <map>
 
 #include "crc32_fast.hpp"
+#include "gz_parallel.hpp"
 #include "inflate.hpp"
+#include "inflate_spec.hpp"
 
 namespace ntsm {
 
@@ -70,9 +72,14 @@ size_t bgzf_member_size(const uint8_t *p, size_t n)
 }
 
 std::atomic<unsigned> g_decoder_threads { 1 };
+std::atomic<size_t> g_parallel_chunk { 2u << 20 };
+std::atomic<uint64_t> g_par_spliced { 0 }, g_par_dropped { 0 };
 } // namespace
 
+void GzStream::last_parallel_stats(uint64_t out[2]) { out[0] = g_par_spliced; out[1] = g_par_dropped; }
+
 void GzStream::set_decoder_threads(unsigned n) { g_decoder_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
+void GzStream::set_parallel_chunk(size_t bytes) { g_parallel_chunk = bytes ? std::max<size_t>(bytes, 1024) : (2u << 20); }
 
 bool GzStream::is_gzip(const std::string &path)
 {
@@ -134,7 +141,7 @@ std::unique_ptr<GzStream::Piece> GzStream::blank()
 		if (!m_free.empty()) {
 			std::unique_ptr<Piece> p = std::move(m_free.front());
 			m_free.pop_front();
-			p->len = 0; p->member_end = false; p->status = 0; p->checked = false;
+			p->len = 0; p->member_end = false; p->status = 0; p->checked = false; p->have_crc = false; p->ready = true;
 			return p;
 		}
 	}
@@ -160,7 +167,9 @@ void GzStream::produce()
 	std::vector<uint8_t> work(kWindow + kPiece + kSlack);
 	Inflate inf;
 	const uint8_t *p = m_map, *const end = m_map + m_size;
+	std::unique_ptr<Parallel> par;
 	auto finish = [&](int status) {
+		if (par) { g_par_spliced = par->spliced; g_par_dropped = par->dropped; }
 		std::unique_ptr<Piece> e = blank();
 		e->status = status;
 		push(std::move(e));
@@ -173,6 +182,9 @@ void GzStream::produce()
 		if (q != p) first = false;
 		p = q;
 	}
+	/* one long deflate stream (everything that is not BGZF): chunk workers decode ahead, this thread splices (gz_parallel.hpp) */
+	const size_t chunk = g_parallel_chunk;
+	if (n_threads > 1 && (size_t) (end - p) >= 2 * chunk) par.reset(new Parallel(this, n_threads, chunk));
 	for (;;) {
 		/* member header (the first one was recognised by its magic; later ones: anything else is trailing garbage) */
 		if (p == end) { finish(1); return; }
@@ -183,7 +195,9 @@ void GzStream::produce()
 		if (h == 0) { finish(-1); return; }
 		inf.reset(p + h, end);
 		size_t out = 0, sent = 0;                              /* work[0, out) = this member's recent output */
+		bool member_done = false;
 		for (;;) {
+			if (par) inf.set_stop(m_map, par->target(inf.bit_pos(m_map)));
 			const Inflate::Status st = inf.run(work.data(), &out, kWindow + kPiece);
 			if (out > sent) {
 				std::unique_ptr<Piece> pc = blank();
@@ -200,11 +214,50 @@ void GzStream::produce()
 				}
 				continue;
 			}
+			if (st == Inflate::BLOCK_STOP) {
+				/* A block ended at or beyond the stop bit.  If a finished chunk starts at exactly this bit and a full window of
+				 * this member's output is at hand, its symbols become bytes (markers -> window bytes) and decoding continues where
+				 * the chunk ended; otherwise the next target is asked for at the top of the loop. */
+				const uint64_t pos = inf.bit_pos(m_map);
+				if (par->target(pos) != pos) continue;
+				std::unique_ptr<Parallel::Chunk> c = par->take();
+				if (inf.total_out() < kWindow || out < kWindow) continue;   /* starts here, but this member has no full window yet: dropped */
+				const uint8_t *const win = work.data() + out - kWindow;
+				const size_t n = c->n_sym;
+				const uint16_t *const sym = c->sym.data() + kWindow;
+				uint8_t next_win[kWindow];
+				if (n >= kWindow) SpecInflate::resolve(sym + n - kWindow, kWindow, win, kWindow, next_win);
+				else {
+					memcpy(next_win, win + n, kWindow - n);
+					SpecInflate::resolve(sym, n, win, kWindow, next_win + kWindow - n);
+				}
+				const uint64_t e_bit = c->e_bit, total = inf.total_out() + n;
+				const bool hit_final = c->hit_final;
+				if (n) {
+					std::unique_ptr<Piece> pc = blank();
+					pc->len = n;
+					if (pc->data.size() < n) pc->data.resize(n);
+					pc->have_crc = true;
+					pc->ready = false;
+					Piece *raw = pc.get();
+					par->resolve_async(std::move(c), win, raw);    /* copies the window; fills raw->data, raw->crc, sets ready */
+					if (!push(std::move(pc))) return;
+				}
+				memcpy(work.data(), next_win, kWindow);
+				out = sent = kWindow;
+				if (hit_final) {                                   /* the chunk ran to the end of the member's last block */
+					p = m_map + (e_bit + 7) / 8;
+					member_done = true;
+					break;
+				}
+				inf.reset_at(m_map + e_bit / 8, (unsigned) (e_bit & 7u), end, total);
+				continue;
+			}
 			if (st == Inflate::TRUNCATED) { finish(1); return; }
 			if (st == Inflate::DATA_ERROR) { finish(-1); return; }
 			break;                                              /* STREAM_END */
 		}
-		p = inf.in();
+		if (!member_done) p = inf.in();
 		if (end - p < 8) { finish(1); return; }               /* truncated trailer: like a truncated stream */
 		std::unique_ptr<Piece> t = blank();
 		t->member_end = true;
@@ -334,7 +387,7 @@ int GzStream::read(void *dst, unsigned len)
 		if (!m_cur) {
 			if (m_final) break;
 			std::unique_lock<std::mutex> lk(m_mu);
-			m_cv.wait(lk, [&]() { return !m_ready.empty(); });
+			m_cv.wait(lk, [&]() { return !m_ready.empty() && m_ready.front()->ready; });
 			m_cur = std::move(m_ready.front());
 			m_ready.pop_front();
 			lk.unlock();
@@ -344,7 +397,12 @@ int GzStream::read(void *dst, unsigned len)
 		const size_t n = std::min<size_t>(len - got, m_cur->len - m_off);
 		if (n) {
 			memcpy(d + got, m_cur->data.data() + m_off, n);
-			if (!m_cur->checked) {
+			if (m_cur->have_crc) {                               /* a spliced chunk: its CRC came with it, once for the whole piece */
+				if (m_off == 0) {
+					m_crc = (uint32_t) crc32_combine(m_crc, m_cur->crc, (z_off_t) m_cur->len);
+					m_len += m_cur->len;
+				}
+			} else if (!m_cur->checked) {
 				m_crc = crc32_fast(m_crc, d + got, n);
 				m_len += n;
 			}

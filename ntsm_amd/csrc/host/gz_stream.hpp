@@ -14,6 +14,16 @@
  * worker threads (each member: own Inflate, CRC-32 and length checked by the worker) and passes the finished groups
  * on in file order; at the first member that is not BGZF, is incomplete or fails, the sequential decoder takes over
  * at that byte, so every input keeps the single-thread semantics.
+ *
+ * An ordinary gzip file (one long deflate stream) is decoded in parallel as well (gz_parallel.cpp, inflate_spec.hpp): the
+ * compressed bytes are cut into chunks; worker threads find the first dynamic block that starts inside their chunk and
+ * decode from there WITHOUT the 32 KiB window, writing 16-bit symbols in which bytes copied out of the unknown window are
+ * markers; the producer decodes in order from the member's start and, whenever it arrives at a block boundary that is
+ * exactly the start bit of a finished chunk, splices the chunk in: its markers are resolved against the now known window
+ * (by the workers, in parallel, CRC-32 of the bytes included) and the in-order decoder continues where the chunk ended.
+ * A chunk whose start does not coincide, that failed, or that saw no dynamic block is simply dropped -- the in-order
+ * decoder goes through its range itself, which is also what reports truncation and corruption with zlib's bytes and
+ * verdict.  Member CRCs are combined from the per-chunk CRCs (crc32_combine).
  */
 #ifndef NTSM_GZ_STREAM_HPP
 #define NTSM_GZ_STREAM_HPP
@@ -38,6 +48,10 @@ public:
 	static bool is_gzip(const std::string &path);      /* regular file that starts with 1f 8b */
 	/* decoder threads used for BGZF input by streams opened from now on (process-wide; default 1 = sequential) */
 	static void set_decoder_threads(unsigned n);
+	/* compressed bytes per chunk of the parallel decoder for plain gzip (process-wide; default 2 MiB; 0 = default) */
+	static void set_parallel_chunk(size_t bytes);
+	/* what the most recently finished parallel decode did (process-wide, for tests and -v): chunks spliced / dropped */
+	static void last_parallel_stats(uint64_t out[2]);
 	bool open(const std::string &path);
 	int read(void *dst, unsigned len);
 	void close();
@@ -48,10 +62,14 @@ private:
 		size_t len = 0;
 		bool member_end = false;                       /* after these bytes a member ends: check crc / isize */
 		bool checked = false;                          /* BGZF group: the workers verified crc / isize already */
+		bool have_crc = false;                         /* parallel plain gzip: `crc` is the CRC-32 of these len bytes (combined by the reader) */
+		bool ready = true;                             /* false: queued in order, a worker is still filling it (guarded by m_mu) */
 		uint32_t crc = 0, isize = 0;
 		int status = 0;                                /* after these bytes: 0 = more, 1 = end of data, -1 = error */
 	};
 	void produce();
+	struct Parallel;                                   /* gz_parallel.cpp: chunk workers of the parallel plain-gzip decoder */
+	friend struct Parallel;
 	const uint8_t *produce_bgzf(const uint8_t *p, unsigned n_threads);   /* returns where the sequential decoder continues, nullptr: reader gone */
 	bool push(std::unique_ptr<Piece> p);               /* false: reader went away */
 	std::unique_ptr<Piece> blank();

@@ -87,6 +87,9 @@ uint64_t ntsm_host_pack2_append(uint8_t *codes, uint8_t *valid, uint64_t pos, co
 }
 const char *ntsm_host_pack2_impl(void) { return ntsm::pack2_impl(); }
 
+void ntsm_host_gunzip_parallel_chunk(uint64_t bytes) { ntsm::GzStream::set_parallel_chunk((size_t) bytes); }
+void ntsm_host_gunzip_parallel_stats(uint64_t stats[2]) { ntsm::GzStream::last_parallel_stats(stats); }
+
 int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out, uint64_t *len)
 {
 	std::vector<uint8_t> all, buf(chunk ? chunk : 1);

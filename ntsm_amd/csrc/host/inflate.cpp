@@ -6,8 +6,7 @@ namespace ntsm {
 
 namespace {
 
-/* table entry: bits 0-4 = bits to consume, 8-11 = extra bits (or sub-table bits), 12-15 = flags, 16-31 = value */
-constexpr uint32_t F_LIT = 0x8000u, F_EOB = 0x4000u, F_SUB = 0x2000u, F_ERR = 0x1000u;
+constexpr uint32_t F_LIT = Inflate::F_LIT, F_EOB = Inflate::F_EOB, F_SUB = Inflate::F_SUB, F_ERR = Inflate::F_ERR;
 constexpr uint32_t kErr = F_ERR | 1u;
 
 const uint16_t kLenBase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
@@ -115,6 +114,19 @@ void Inflate::reset(const uint8_t *in, const uint8_t *in_end)
 	m_last = false;
 	m_stored = 0;
 	m_total = 0;
+	m_base = nullptr;
+	m_stop_bit = 0;
+}
+
+void Inflate::reset_at(const uint8_t *in, unsigned bit, const uint8_t *in_end, uint64_t total)
+{
+	reset(in, in_end);
+	m_total = total;
+	if (bit && in < in_end) {                                  /* the rest of the first byte goes into the bit buffer */
+		m_bb = (uint64_t) *in >> bit;
+		m_bc = 8 - bit;
+		m_in = in + 1;
+	}
 }
 
 const uint8_t *Inflate::in() const { return m_in - (m_bc >> 3); }
@@ -313,6 +325,41 @@ NTSM_INFLATE_CLONES Inflate::Status Inflate::run_huffman(uint8_t *buf, size_t *o
 #undef SAVE
 }
 
+Inflate::Status Inflate::open_block()
+{
+	NTSM_REFILL_SAFE();
+	if (m_bc < 3) return TRUNCATED;
+	m_last = (m_bb & 1u) != 0;
+	const unsigned type = (unsigned) (m_bb >> 1) & 3u;
+	NTSM_TAKE(3);
+	if (type == 0) {
+		NTSM_TAKE(m_bc & 7u);                             /* skip to the byte boundary */
+		NTSM_REFILL_SAFE();
+		if (m_bc < 32) return TRUNCATED;
+		const uint32_t len = (uint32_t) (m_bb & 0xFFFFu), nlen = (uint32_t) ((m_bb >> 16) & 0xFFFFu);
+		if ((len ^ 0xFFFFu) != nlen) { m_mode = DONE; return DATA_ERROR; }   /* "invalid stored block lengths" */
+		NTSM_TAKE(32);
+		m_stored = len;
+		m_mode = STORED;
+	} else if (type == 1) {
+		set_fixed();
+		m_mode = HUFFMAN;
+	} else if (type == 2) {
+		m_stored = 0;
+		if (!read_dynamic_header()) {
+			const bool trunc = m_stored == 0xFFFFFFFFu;
+			m_stored = 0;
+			m_mode = DONE;
+			return trunc ? TRUNCATED : DATA_ERROR;
+		}
+		m_mode = HUFFMAN;
+	} else {
+		m_mode = DONE;
+		return DATA_ERROR;                                /* "invalid block type" */
+	}
+	return MORE;
+}
+
 Inflate::Status Inflate::run(uint8_t *buf, size_t *out, size_t out_stop)
 {
 	for (;;) {
@@ -321,36 +368,9 @@ Inflate::Status Inflate::run(uint8_t *buf, size_t *out, size_t out_stop)
 			return STREAM_END;
 		case HEADER: {
 			if (m_last) { m_mode = DONE; return STREAM_END; }
-			NTSM_REFILL_SAFE();
-			if (m_bc < 3) return TRUNCATED;
-			m_last = (m_bb & 1u) != 0;
-			const unsigned type = (unsigned) (m_bb >> 1) & 3u;
-			NTSM_TAKE(3);
-			if (type == 0) {
-				NTSM_TAKE(m_bc & 7u);                             /* skip to the byte boundary */
-				NTSM_REFILL_SAFE();
-				if (m_bc < 32) return TRUNCATED;
-				const uint32_t len = (uint32_t) (m_bb & 0xFFFFu), nlen = (uint32_t) ((m_bb >> 16) & 0xFFFFu);
-				if ((len ^ 0xFFFFu) != nlen) { m_mode = DONE; return DATA_ERROR; }   /* "invalid stored block lengths" */
-				NTSM_TAKE(32);
-				m_stored = len;
-				m_mode = STORED;
-			} else if (type == 1) {
-				set_fixed();
-				m_mode = HUFFMAN;
-			} else if (type == 2) {
-				m_stored = 0;
-				if (!read_dynamic_header()) {
-					const bool trunc = m_stored == 0xFFFFFFFFu;
-					m_stored = 0;
-					m_mode = DONE;
-					return trunc ? TRUNCATED : DATA_ERROR;
-				}
-				m_mode = HUFFMAN;
-			} else {
-				m_mode = DONE;
-				return DATA_ERROR;                                /* "invalid block type" */
-			}
+			if (m_base && bit_pos(m_base) >= m_stop_bit) return BLOCK_STOP;
+			const Status st = open_block();
+			if (st != MORE) return st;
 			break;
 		}
 		case STORED: {

@@ -33,12 +33,23 @@ public:
 		MORE,          /* stopped because the output position reached out_stop; call again */
 		STREAM_END,    /* the final block ended; in() is the first byte after the deflate stream (byte aligned) */
 		TRUNCATED,     /* the input ended inside the stream; everything decodable has been written */
-		DATA_ERROR     /* invalid stream */
+		DATA_ERROR,    /* invalid stream */
+		BLOCK_STOP     /* set_stop(): a block just ended at or beyond the stop position; the next header is unread */
 	};
 
 	/* Start a new deflate stream at [in, in_end).  `window` = number of bytes before the current output position
 	 * that belong to this stream (0 at the start of a gzip member). */
 	void reset(const uint8_t *in, const uint8_t *in_end);
+	/* The same in the middle of a stream (parallel gzip decoding, gz_parallel.cpp): the next block header starts `bit`
+	 * bits (0..7) into *in, and `total` bytes of this stream have been produced before it (the caller keeps the last
+	 * 32 KiB of them in front of the output position). */
+	void reset_at(const uint8_t *in, unsigned bit, const uint8_t *in_end, uint64_t total);
+	/* Make run() return BLOCK_STOP at the first block boundary whose bit offset from `base` is >= stop_bit (checked
+	 * before every block header, the first one included).  base = nullptr: never (the default after reset()). */
+	void set_stop(const uint8_t *base, uint64_t stop_bit) { m_base = base; m_stop_bit = stop_bit; }
+	/* bit offset of the next unread bit from `base`; valid between run() calls */
+	uint64_t bit_pos(const uint8_t *base) const { return (uint64_t) (m_in - base) * 8u - m_bc; }
+	bool last_block_seen() const { return m_last; }
 
 	/* Decode into buf (the bytes [0, *out) already hold this stream's history as far as it exists) until *out >=
 	 * out_stop or the stream ends.  A call may write up to 258 + 8 bytes past out_stop. */
@@ -47,13 +58,18 @@ public:
 	const uint8_t *in() const;          /* next unread input byte (valid after STREAM_END: bit buffer returned) */
 	uint64_t total_out() const { return m_total; }   /* bytes produced since reset() */
 
-private:
+	/* decode-table entry: bits 0-4 = bits to consume, 8-11 = extra bits (or sub-table bits), 12-15 = flags, 16-31 = value */
+	static constexpr uint32_t F_LIT = 0x8000u, F_EOB = 0x4000u, F_SUB = 0x2000u, F_ERR = 0x1000u;
+
+protected:
 	static constexpr int kLitBits = 11, kDistBits = 8;
 	static constexpr int kLitSize = (1 << kLitBits) + 1024, kDistSize = (1 << kDistBits) + 512;
 	enum Mode { HEADER, STORED, HUFFMAN, DONE };
 	bool build(uint32_t *table, int table_bits, int max_size, const uint8_t *lens, int n, bool is_dist);
 	bool read_dynamic_header();
 	void set_fixed();
+	/* one block header at the current position: MORE = a block is open (m_mode STORED / HUFFMAN), else the status to return */
+	Status open_block();
 	NTSM_INFLATE_CLONES Status run_huffman(uint8_t *buf, size_t *out, size_t out_stop);
 
 	const uint8_t *m_in = nullptr, *m_end = nullptr;
@@ -63,6 +79,8 @@ private:
 	bool m_last = false;
 	uint32_t m_stored = 0;
 	uint64_t m_total = 0;
+	const uint8_t *m_base = nullptr;
+	uint64_t m_stop_bit = 0;
 	uint32_t m_lit[kLitSize], m_dist[kDistSize];
 };
 

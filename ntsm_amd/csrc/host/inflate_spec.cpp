@@ -1,0 +1,250 @@
+#include "inflate_spec.hpp"
+
+#include <algorithm>
+#include <cstring>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace ntsm {
+
+namespace {
+inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline void store64(void *p, uint64_t v) { memcpy(p, &v, 8); }
+} // namespace
+
+void SpecInflate::fill_markers(uint16_t *sym)
+{
+	for (size_t j = 0; j < kWindow; ++j) sym[j] = (uint16_t) (kMarker | j);
+}
+
+/* Candidate filter in registers, then the full header parse of Inflate::open_block (the same checks the in-order decoder
+ * applies).  The filter: BFINAL = 0, BTYPE = 2, HLIT <= 29, HDIST <= 29, and a precode whose lengths satisfy Kraft's
+ * equality (zlib rejects an incomplete precode, inftrees.c). */
+uint64_t SpecInflate::find(const uint8_t *base, const uint8_t *end, uint64_t from_bit, uint64_t to_bit)
+{
+	const uint64_t size_bits = (uint64_t) (end - base) * 8u;
+	if (size_bits < 20 * 8) return ~0ull;
+	const uint64_t last = std::min<uint64_t>(to_bit, size_bits - 18 * 8);    /* two 64-bit loads stay inside the input */
+	for (uint64_t b = from_bit; b < last; ++b) {
+		const uint8_t *p = base + (b >> 3);
+		const unsigned sh = (unsigned) (b & 7u);
+		const uint64_t x = load64(p) >> sh;                                   /* >= 57 valid bits */
+		if ((x & 7u) != 4u) continue;                                         /* BFINAL = 0, BTYPE = 10b */
+		if (((x >> 3) & 31u) > 29u || ((x >> 8) & 31u) > 29u) continue;
+		const unsigned ncode = (unsigned) ((x >> 13) & 15u) + 4u;
+		/* precode lengths: 3 bits each from bit 17 of the candidate, up to 19 of them (bits 17 .. 73) */
+		unsigned __int128 z = ((((unsigned __int128) load64(p + 8)) << 64) | load64(p)) >> (sh + 17);
+		unsigned kraft = 0, used = 0;
+		for (unsigned i = 0; i < ncode; ++i) {
+			const unsigned l = (unsigned) z & 7u;
+			z >>= 3;
+			if (l) { kraft += 128u >> l; ++used; }
+		}
+		if (kraft != 128u || used < 2) continue;
+		reset_at(p, sh, end, 0);
+		if (open_block() != MORE || m_last || m_mode != HUFFMAN) continue;
+		return b;
+	}
+	return ~0ull;
+}
+
+NTSM_INFLATE_CLONES Inflate::Status SpecInflate::run_huffman16(uint16_t *buf, size_t *out, size_t out_stop)
+{
+	const uint8_t *in = m_in;
+	uint64_t bb = m_bb;
+	unsigned bc = m_bc;
+	uint16_t *op = buf + *out;
+	uint16_t *const op0 = op, *const op_stop = buf + out_stop;
+	const uint64_t total0 = m_total;
+	Status st = MORE;
+	constexpr uint32_t lmask = (1u << kLitBits) - 1, dmask = (1u << kDistBits) - 1;
+#define SAVE() do { m_in = in; m_bc = bc; m_bb = bc >= 64 ? bb : (bb & ((1ull << bc) - 1)); \
+		m_total = total0 + (uint64_t) (op - op0); *out = (size_t) (op - buf); } while (0)
+	if (m_end - in >= 16 && op_stop - op > 280) {
+		const uint8_t *const in_fast = m_end - 16;
+		uint16_t *const op_fast = op_stop - 280;
+		while (in < in_fast && op < op_fast) {
+			bb |= load64(in) << bc;
+			in += (63 - bc) >> 3;
+			bc |= 56;
+			uint32_t e = m_lit[bb & lmask];
+			if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
+			bb >>= (e & 31u); bc -= (e & 31u);
+			if (e & F_LIT) {
+				*op++ = (uint16_t) (e >> 16);
+				e = m_lit[bb & lmask];
+				if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
+				bb >>= (e & 31u); bc -= (e & 31u);
+				if (e & F_LIT) {
+					*op++ = (uint16_t) (e >> 16);
+					e = m_lit[bb & lmask];
+					if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
+					bb >>= (e & 31u); bc -= (e & 31u);
+					if (e & F_LIT) { *op++ = (uint16_t) (e >> 16); continue; }
+				}
+			}
+			if (e & (F_EOB | F_ERR)) {
+				SAVE();
+				return (e & F_ERR) ? DATA_ERROR : STREAM_END;
+			}
+			const unsigned lx = (e >> 8) & 15u;
+			const uint32_t len = (e >> 16) + (uint32_t) (bb & ((1u << lx) - 1));
+			bb >>= lx; bc -= lx;
+			bb |= load64(in) << bc;
+			in += (63 - bc) >> 3;
+			bc |= 56;
+			uint32_t d = m_dist[bb & dmask];
+			if (d & F_SUB) { bb >>= kDistBits; bc -= kDistBits; d = m_dist[(d >> 16) + (uint32_t) (bb & ((1u << ((d >> 8) & 15u)) - 1))]; }
+			bb >>= (d & 31u); bc -= (d & 31u);
+			if (d & F_ERR) { SAVE(); return DATA_ERROR; }
+			const unsigned dx = (d >> 8) & 15u;
+			const uint32_t dist = (d >> 16) + (uint32_t) (bb & ((1u << dx) - 1));
+			bb >>= dx; bc -= dx;
+			/* dist <= 32768 always lands inside the buffer: its first kWindow symbols are the markers */
+			const uint16_t *src = op - dist;
+			uint16_t *const end = op + len;
+			if (dist >= 4) {
+				do { store64(op, load64((const uint8_t *) src)); op += 4; src += 4; } while (op < end);
+			} else if (dist == 1) {
+				const uint64_t v = 0x0001000100010001ull * *src;
+				do { store64(op, v); op += 4; } while (op < end);
+			} else {
+				do { *op++ = *src++; } while (op < end);
+			}
+			op = end;
+		}
+	}
+	while (op < op_stop) {
+		while (bc <= 56 && in < m_end) { bb |= (uint64_t) *in++ << bc; bc += 8; }
+		uint32_t e = m_lit[bb & lmask];
+		if (e & F_SUB) {
+			if (bc < (unsigned) kLitBits) { st = TRUNCATED; break; }
+			bb >>= kLitBits; bc -= kLitBits;
+			e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))];
+		}
+		if ((e & 31u) > bc || ((e & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
+		if (e & F_ERR) { st = DATA_ERROR; break; }
+		bb >>= (e & 31u); bc -= (e & 31u);
+		if (e & F_LIT) { *op++ = (uint16_t) (e >> 16); continue; }
+		if (e & F_EOB) { st = STREAM_END; break; }
+		const unsigned lx = (e >> 8) & 15u;
+		if (bc < lx) { st = TRUNCATED; break; }
+		const uint32_t len = (e >> 16) + (uint32_t) (bb & ((1u << lx) - 1));
+		bb >>= lx; bc -= lx;
+		while (bc <= 56 && in < m_end) { bb |= (uint64_t) *in++ << bc; bc += 8; }
+		uint32_t d = m_dist[bb & dmask];
+		if (d & F_SUB) {
+			if (bc < (unsigned) kDistBits) { st = TRUNCATED; break; }
+			bb >>= kDistBits; bc -= kDistBits;
+			d = m_dist[(d >> 16) + (uint32_t) (bb & ((1u << ((d >> 8) & 15u)) - 1))];
+		}
+		if ((d & 31u) > bc || ((d & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
+		if (d & F_ERR) { st = DATA_ERROR; break; }
+		bb >>= (d & 31u); bc -= (d & 31u);
+		const unsigned dx = (d >> 8) & 15u;
+		if (bc < dx) { st = TRUNCATED; break; }
+		const uint32_t dist = (d >> 16) + (uint32_t) (bb & ((1u << dx) - 1));
+		bb >>= dx; bc -= dx;
+		const uint16_t *src = op - dist;
+		for (uint32_t i = 0; i < len; ++i) op[i] = src[i];
+		op += len;
+	}
+	SAVE();
+	return st;
+#undef SAVE
+}
+
+Inflate::Status SpecInflate::run16(uint16_t *sym, size_t *out, size_t out_stop)
+{
+	for (;;) {
+		switch (m_mode) {
+		case DONE:
+			return STREAM_END;
+		case HEADER: {
+			if (m_last) { m_mode = DONE; return STREAM_END; }
+			if (m_base && bit_pos(m_base) >= m_stop_bit) return BLOCK_STOP;
+			const Status st = open_block();
+			if (st != MORE) return st;
+			break;
+		}
+		case STORED: {
+			while (m_stored && m_bc) {
+				if (*out >= out_stop) return MORE;
+				sym[(*out)++] = (uint16_t) (m_bb & 0xFFu);
+				m_bb >>= 8; m_bc -= 8;
+				--m_stored;
+				++m_total;
+			}
+			if (m_stored) {
+				if (*out >= out_stop) return MORE;
+				size_t n = m_stored;
+				if (n > (size_t) (m_end - m_in)) n = (size_t) (m_end - m_in);
+				if (n > out_stop - *out) n = out_stop - *out;
+				for (size_t i = 0; i < n; ++i) sym[*out + i] = m_in[i];
+				m_in += n;
+				*out += n;
+				m_total += n;
+				m_stored -= (uint32_t) n;
+				if (m_stored) return m_in == m_end ? TRUNCATED : MORE;
+			}
+			m_mode = HEADER;
+			break;
+		}
+		case HUFFMAN: {
+			const Status st = run_huffman16(sym, out, out_stop);
+			if (st == STREAM_END) { m_mode = HEADER; break; }
+			if (st == DATA_ERROR) m_mode = DONE;
+			return st;
+		}
+		}
+	}
+}
+
+namespace {
+bool resolve_scalar(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out)
+{
+	const uint16_t lowest = (uint16_t) (SpecInflate::kMarker | (SpecInflate::kWindow - valid));
+	bool ok = true;
+	for (size_t i = 0; i < n; ++i) {
+		const uint16_t s = sym[i];
+		if (s < 256) out[i] = (uint8_t) s;
+		else {
+			ok &= s >= lowest;
+			out[i] = window[s & 0x7FFFu];
+		}
+	}
+	return ok;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) bool resolve_avx2(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out)
+{
+	const __m256i hi = _mm256_set1_epi16((short) 0xFF00);
+	bool ok = true;
+	size_t i = 0;
+	for (; i + 32 <= n; i += 32) {
+		const __m256i a = _mm256_loadu_si256((const __m256i *) (sym + i));
+		const __m256i b = _mm256_loadu_si256((const __m256i *) (sym + i + 16));
+		if (_mm256_testz_si256(_mm256_or_si256(a, b), hi)) {       /* 32 literals */
+			const __m256i p = _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8);
+			_mm256_storeu_si256((__m256i *) (out + i), p);
+		} else {
+			ok &= resolve_scalar(sym + i, 32, window, valid, out + i);
+		}
+	}
+	ok &= resolve_scalar(sym + i, n - i, window, valid, out + i);
+	return ok;
+}
+#endif
+} // namespace
+
+bool SpecInflate::resolve(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out)
+{
+#if defined(__x86_64__)
+	static const bool avx2 = __builtin_cpu_supports("avx2");
+	if (avx2) return resolve_avx2(sym, n, window, valid, out);
+#endif
+	return resolve_scalar(sym, n, window, valid, out);
+}
+
+} // namespace ntsm

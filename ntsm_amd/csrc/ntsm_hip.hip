@@ -103,6 +103,33 @@ __device__ __forceinline__ unsigned long long ntsm_read_of(const NtsmCountParams
 	return lo;
 }
 
+/* Counter update of the lanes that found their k-mer (slot >= 0; every lane of the wave must call this together).
+ * One 64-bit atomic per hit -- unless lanes of this wave hit the SAME counter (low-complexity input whose k-mer is a site
+ * k-mer: every lane, every time): equal slots are added up inside the wave first.  Rounds: the lowest lane that still has
+ * a hit broadcasts its slot, the lanes with that slot are counted by a ballot and leave, the lowest lane adds their number.
+ * A round that finds a single lane ends the search (ordinary traffic: hits spread over 1.5 M counters, one round of ~8
+ * scalar / vector instructions); whoever is left adds 1 by itself.  src/FingerPrint.hpp:94-95 (`m_counts[*itr] += 1`
+ * under `omp atomic`) with the same result: integer adds commute. */
+__device__ __forceinline__ void ntsm_add_hits(const NtsmCountParams &p, long long slot, int lane)
+{
+	bool act = slot >= 0;
+	unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+	while (am) {
+		const int leader = __builtin_ctzll(am);
+		const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) slot, leader);
+		const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) ((unsigned long long) slot >> 32), leader);
+		const bool same = act && (uint32_t) slot == lo && (uint32_t) ((unsigned long long) slot >> 32) == hi;
+		const unsigned long long grp = __builtin_amdgcn_ballot_w64(same);
+		const unsigned long long cnt = (unsigned long long) __popcll(grp);
+		if (lane == leader)
+			__hip_atomic_fetch_add(ntsm_count_ptr(p.keys, slot), p.sign * cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		act = act && !same;
+		am &= ~grp;
+		if (cnt == 1) break;
+	}
+	if (act) __hip_atomic_fetch_add(ntsm_count_ptr(p.keys, slot), p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int C, bool PER_READ>
 __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(const NtsmCountParams p)
 {
@@ -202,17 +229,16 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const int i = 4 * s + j;
+					long long slot = -1;
 					if (pos[j]) {
 						const uint32_t klo = (uint32_t) cn[i], khi = (uint32_t) (cn[i] >> 32);
 						const unsigned long long b1 = 2ull * (ntsm_h1(hh[i]) >> bshift);
 						const unsigned long long b2 = 2ull * (ntsm_h2(hh[i]) >> bshift);
-						long long slot = -1;
 						if (ba[j].x == klo && ba[j].y == khi) slot = (long long) b1;
 						else if (ba[j].z == klo && ba[j].w == khi) slot = (long long) b1 + 1;
 						else if (bb[j].x == klo && bb[j].y == khi) slot = (long long) b2;
 						else if (bb[j].z == klo && bb[j].w == khi) slot = (long long) b2 + 1;
 						if (slot >= 0) {
-							__hip_atomic_fetch_add(ntsm_count_ptr(p.keys, slot), p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							++nh;
 							if (PER_READ) {
 								const unsigned long long pb = (unsigned long long) (ts + (long long) t * C + 8 * g + i);
@@ -220,6 +246,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(
 							}
 						}
 					}
+					ntsm_add_hits(p, slot, t & 63);                   /* all lanes: equal slots inside the wave are added up first */
 				}
 			}
 		}
@@ -449,6 +476,7 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		bool s1_v = false, s2_v = false;
 		auto drain_step = [&](bool take) {
 			/* stage 3 */
+			long long slot_of_hit = -1;
 			if (s2_v) {
 				long long slot = -1;
 				if (s2_ba.x == s2_klo && s2_ba.y == s2_khi) slot = (long long) s2_b1;
@@ -461,14 +489,15 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 					else if (bb.z == s2_klo && bb.w == s2_khi) slot = (long long) b2 + 1;
 				}
 				if (slot >= 0) {
-#ifdef NTSM_ABLATION
-					if (!(p.debug & 4u))
-#endif
-						__hip_atomic_fetch_add(ntsm_count_ptr(p.keys, slot), p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					++nh;
 					if (PER_READ) atomicAdd(p.read_hits + ntsm_read_of(p, (unsigned long long) (ts + (long long) s2_pos)), 1u);
 				}
+				slot_of_hit = slot;
 			}
+#ifdef NTSM_ABLATION
+			if (!(p.debug & 4u))
+#endif
+			ntsm_add_hits(p, slot_of_hit, lane);                   /* equal slots inside the wave are added up first */
 			/* stage 2 */
 			s2_v = s1_v && (((s1_pw >> (s1_g2 & 31u)) & (s1_pw >> ((s1_g2 >> 5) & 31u)) & 1u) != 0);
 #ifdef NTSM_ABLATION

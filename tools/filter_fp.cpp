@@ -32,8 +32,9 @@ int main(int argc, char **argv)
 {
 	ntsm::SiteSet S;
 	if (argc < 2 || !S.load(argv[1], 19, false, std::cerr)) return 1;
-	const uint32_t e = 16; NtsmBlockMap map; map.n_blocks = 3u << e;   /* 3 * 2^16 blocks (3 MiB) */
-	const uint64_t n_blocks = 3ull << e;
+	const uint64_t n_blocks = argc > 2 ? (uint64_t) atoll(argv[2]) * 64 : 3ull << 16;   /* argv[2]: filter size in KiB (default 3 MiB = 3 * 2^16 blocks) */
+	NtsmBlockMap map; map.n_blocks = (uint32_t) n_blocks;
+	printf("%zu site k-mers, %llu blocks = %.2f MiB, %.2f bits per key\n", S.keys.size(), (unsigned long long) n_blocks, n_blocks / 65536.0, n_blocks * 128.0 / S.keys.size());
 	std::vector<Scheme> schemes = {
 		{ "A: 4 words x 1 bit (current)", 0, 0, 0 },
 		{ "A-ideal: 4 words x 1 bit, four independent 64-bit-mixed hashes", 5, 0, 0 },
