@@ -16,7 +16,8 @@ Prints ONE JSON line (rank 0).  `roofline` is for the count kernel: algorithmic 
  over the HIP-event launch time; `cpu_baseline` is the reference's CPU path timed on a bounded sample of
 the same reads.  At N = 1 the line also carries `other_configs`: BASELINE.json configs[2] (long reads, with and
 without -m 10), configs[4] (1 M sites) and the file -> counts.txt path through build/ntsmCount, each with its own
-correctness check.
+correctness check; `n10_full` is the same measurement at the upper bound of the real sites file's size
+(2.5 M site k-mers).
 """
 import argparse
 import hashlib
@@ -31,8 +32,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r03_traffic.json"          # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
-STRESS_TRAFFIC_FILE = "r03_stress_traffic.json"
+TRAFFIC_FILE = "r04_traffic.json"          # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
+STRESS_TRAFFIC_FILE = "r04_stress_traffic.json"
+N10_FULL_TRAFFIC_FILE = "r04_n10_full_traffic.json"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 SITES_SEED, N_SITES, READ_SEED, READ_LEN, K = 20241218, 96287, 7, 150, 19
 
@@ -50,11 +52,13 @@ def parse_args(argv=None):
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (minimizer-blocked kernel for k=19), 1 generic")
     ap.add_argument("--no-check", action="store_true", help="skip the correctness check of the timed result")
-    ap.add_argument("--other-configs", default="long,stress,e2e",
+    ap.add_argument("--other-configs", default="long,stress,n10_full,e2e",
                     help="comma list of the secondary single-GPU measurements appended at N = 1 ('' or 'none': skip)")
     ap.add_argument("--long-reads", type=float, default=5e6)
     ap.add_argument("--stress-sites", type=float, default=1e6)
     ap.add_argument("--stress-reads", type=float, default=2e8)
+    ap.add_argument("--n10-full-sites", type=float, default=N_SITES)
+    ap.add_argument("--n10-full-reads", type=float, default=2e8)
     ap.add_argument("--e2e-reads", type=float, default=4e7, help="reads of the FASTQ the CLI leg counts (4e7 = 12.6 GB)")
     ap.add_argument("--e2e-threads", type=int, default=16)
     ap.add_argument("--dry-launch", action="store_true",
@@ -262,17 +266,18 @@ def config_long(nt, torch, dev, local, synth, sites, args):
     return out
 
 
-def config_stress(nt, torch, dev, local, args, tmp):
-    """BASELINE.json configs[4]: 1 M sites (16 M site k-mers, 512 MiB key table), 150 bp reads resident in HBM."""
-    n_sites, n_reads = int(args.stress_sites), int(args.stress_reads)
-    sp = os.path.join(tmp, "stress.fa")
+def config_sites(nt, torch, dev, local, tmp, label, what, sites_seed, n_sites, min_keep, n_reads, traffic_file):
+    """A resident 150 bp stream against another site set: kernel rate, roofline fraction, the whole stream checked against the
+    generic kernel, PMC-derived request counts when a profile of the current kernel sources exists."""
+    sp = os.path.join(tmp, label + ".fa")
     t0 = time.perf_counter()
-    s = nt.SynthShort(424242, n_sites, read_seed=9, sites_path=sp)
+    s = nt.SynthShort(sites_seed, n_sites, read_seed=9, sites_path=sp, min_keep=min_keep)
     sites = nt.Sites(sp, k=K)
     t_sites = time.perf_counter() - t0
     t0 = time.perf_counter()
     ctx = nt.Context(sites.keys, k=K, device=local)
     t_create = time.perf_counter() - t0
+    two_level = ctx.debug_stats()["two_level"]
     d_win = torch.from_numpy(s.windows).to(dev)
     d_bases = torch.empty(n_reads * s.stride, dtype=torch.uint8, device=dev)
     s.device_fill(d_win.data_ptr(), 0, n_reads, d_bases.data_ptr())
@@ -282,23 +287,37 @@ def config_stress(nt, torch, dev, local, args, tmp):
     counts = ctx.counts()
     ctx.close()
     check = {}
-    if not args.no_check:
+    if what["check"]:
         rk, rh, rc = generic_reference(nt, sites.keys, d_bases.data_ptr(), d_bases.numel(), n_reads, local)
         assert (t.total_kmers, t.total_hits) == (reps * rk, reps * rh) and (counts == rc * reps).all(), \
-            "1 M sites: minimizer-blocked kernel and generic kernel disagree"
+            "%s: minimizer-blocked kernel and generic kernel disagree" % label
         check["equals_generic_kernel_on_the_whole_stream"] = True
     bases = n_reads * READ_LEN
-    tj, note = pmc_constants(STRESS_TRAFFIC_FILE)
-    out = {"workload": "configs[4]: %.3g sites (%d site 19-mers), %.3g synthetic 150 bp reads" % (n_sites, len(sites.keys), n_reads),
+    tj, note = pmc_constants(traffic_file)
+    out = {"workload": "%s: %.6g sites (%d site 19-mers), %.3g synthetic 150 bp reads" % (what["name"], n_sites, len(sites.keys), n_reads),
            "reads": n_reads, "site_kmers": len(sites.keys), "kernel_ms": ms, "gbases_per_s": bases / ms / 1e6,
-           "roofline_frac": bases * (READ_LEN + 8) / READ_LEN / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+           "roofline_frac": bases * (READ_LEN + 8) / READ_LEN / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel_form": "two-level" if two_level else "one-level",
            "hits_per_pass": t.total_hits // reps, "site_gen_and_load_s": t_sites, "create_s": t_create,
            "fabric_read_requests_per_base_from_pmc": tj.get("fabric_read_requests_per_base") if tj else None,
-           "l2_requests_per_base_from_pmc": tj.get("l2_requests_per_base") if tj else None, "pmc_source": note,
+           "l2_requests_per_base_from_pmc": tj.get("l2_requests_per_base") if tj else None,
+           "l2_misses_per_base_from_pmc": tj.get("l2_misses_per_base") if tj else None, "pmc_source": note,
            "check": check}
     del d_bases
     torch.cuda.empty_cache()
     return out
+
+
+def config_stress(nt, torch, dev, local, args, tmp):
+    """BASELINE.json configs[4]: 1 M sites (16 M site k-mers, 512 MiB key table), 150 bp reads resident in HBM."""
+    return config_sites(nt, torch, dev, local, tmp, "stress", {"name": "configs[4]", "check": not args.no_check}, 424242, int(args.stress_sites), 0,
+                        int(args.stress_reads), STRESS_TRAFFIC_FILE)
+
+
+def config_n10_full(nt, torch, dev, local, args, tmp):
+    """The worst-case geometry of the real sites file (0.58 - 2.50 M distinct k-mers; data/human_sites_n10.fa
+    is absent): the bench set's 96287 sites with EVERY one of the 13 k-mers of both alleles kept = 2,503,462 site 19-mers."""
+    return config_sites(nt, torch, dev, local, tmp, "n10_full", {"name": "n10_full (upper bound of human_sites_n10.fa: 13 k-mers per allele)", "check": not args.no_check},
+                        SITES_SEED, int(args.n10_full_sites), 13, int(args.n10_full_reads), N10_FULL_TRAFFIC_FILE)
 
 
 def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
@@ -597,6 +616,8 @@ def run_rank(args):
                         other["long"] = config_long(ntsm_amd, torch, dev, local, synth, sites, args)
                     elif name == "stress":
                         other["stress"] = config_stress(ntsm_amd, torch, dev, local, args, tmp)
+                    elif name == "n10_full":
+                        other["n10_full"] = config_n10_full(ntsm_amd, torch, dev, local, args, tmp)
                     elif name == "e2e":
                         other["e2e_cli"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp)
                     else:

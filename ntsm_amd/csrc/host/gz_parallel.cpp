@@ -1,5 +1,9 @@
 #include "gz_parallel.hpp"
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "crc32_fast.hpp"
@@ -10,6 +14,9 @@ namespace ntsm {
 namespace {
 constexpr size_t kWin = SpecInflate::kWindow;
 constexpr size_t kSymSlack = 512;
+/* NTSM_PGZ_PROF=1: where the workers' time goes (find / decode / resolve + crc / waiting), printed when a stream closes */
+std::atomic<uint64_t> g_ns_find { 0 }, g_ns_decode { 0 }, g_ns_resolve { 0 }, g_ns_wait { 0 }, g_sym { 0 };
+inline uint64_t now_ns() { return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 
 GzStream::Parallel::Parallel(GzStream *gz, unsigned n_threads, size_t chunk_bytes)
@@ -33,6 +40,9 @@ GzStream::Parallel::~Parallel()
 	}
 	m_cv.notify_all();
 	for (auto &t : m_pool) t.join();
+	if (getenv("NTSM_PGZ_PROF"))
+		fprintf(stderr, "[pgz] workers: find %.3f s, decode %.3f s (%.1f M symbols), resolve+crc %.3f s, idle %.3f s; spliced %zu dropped %zu\n",
+		        g_ns_find / 1e9, g_ns_decode / 1e9, g_sym / 1e6, g_ns_resolve / 1e9, g_ns_wait / 1e9, spliced, dropped);
 }
 
 /* keep chunks [m_next, m_next + m_depth) with the workers (m_mu held) */
@@ -111,8 +121,11 @@ void GzStream::Parallel::decode_chunk(Chunk &c, SpecInflate &sp)
 	}
 	uint64_t from = s_bit;
 	for (int attempt = 0; attempt < 8; ++attempt) {
+		const uint64_t t0 = now_ns();
 		const uint64_t b = sp.find(m_base, m_end, from, limit);
+		g_ns_find += now_ns() - t0;
 		if (b == ~0ull) return;
+		const uint64_t t1 = now_ns();
 		sp.set_stop(m_base, limit);
 		size_t out = kWin;
 		Inflate::Status st;
@@ -122,6 +135,8 @@ void GzStream::Parallel::decode_chunk(Chunk &c, SpecInflate &sp)
 			if (c.sym.size() > (1ull << 30)) { st = Inflate::DATA_ERROR; break; }      /* 2 GiB of symbols from one chunk: give it to the in-order decoder */
 			c.sym.resize(c.sym.size() * 2);
 		}
+		g_ns_decode += now_ns() - t1;
+		g_sym += out - kWin;
 		if (st == Inflate::BLOCK_STOP || st == Inflate::STREAM_END) {
 			c.found = true;
 			c.hit_final = st == Inflate::STREAM_END;
@@ -139,10 +154,13 @@ void GzStream::Parallel::worker()
 	SpecInflate sp;
 	for (;;) {
 		Resolve r;
+		r.piece = nullptr;
 		Chunk *c = nullptr;
 		{
+			const uint64_t tw = now_ns();
 			std::unique_lock<std::mutex> lk(m_mu);
 			m_cv.wait(lk, [&]() { return m_quit || !m_resolve.empty() || !m_todo.empty(); });
+			g_ns_wait += now_ns() - tw;
 			/* pieces that are already queued for the reader are always filled, also on the way out */
 			if (!m_resolve.empty()) { r = std::move(m_resolve.front()); m_resolve.pop_front(); }
 			else if (m_quit) return;
@@ -160,9 +178,11 @@ void GzStream::Parallel::worker()
 		/* bytes of a spliced chunk: markers -> window bytes, CRC-32 for the member check */
 		Piece *pc = r.piece;
 		const size_t n = r.chunk->n_sym;
+		const uint64_t tr = now_ns();
 		const bool ok = SpecInflate::resolve(r.chunk->sym.data() + kWin, n, r.window.data(), kWin, pc->data.data());
 		pc->crc = crc32_fast(0, pc->data.data(), n);
 		if (!ok) pc->status = -1;                             /* cannot happen: the splice requires a full window */
+		g_ns_resolve += now_ns() - tr;
 		{
 			std::lock_guard<std::mutex> lk(m_mu);
 			m_bufPool.push_back(std::move(r.chunk->sym));

@@ -108,7 +108,8 @@ __device__ __forceinline__ unsigned long long ntsm_read_of(const NtsmCountParams
  * k-mer: every lane, every time): equal slots are added up inside the wave first.  Rounds: the lowest lane that still has
  * a hit broadcasts its slot, the lanes with that slot are counted by a ballot and leave, the lowest lane adds their number.
  * A round that finds a single lane ends the search (ordinary traffic: hits spread over 1.5 M counters, one round of ~8
- * scalar / vector instructions); whoever is left adds 1 by itself.  src/FingerPrint.hpp:94-95 (`m_counts[*itr] += 1`
+ * scalar / vector instructions); whoever is left adds 1 by itself.  (A workgroup-wide LDS accumulator behind this was built and
+ * measured out: inlined or as a call it pushed the k = 19 kernel from 122 VGPRs to 128 + scratch.)  src/FingerPrint.hpp:94-95 (`m_counts[*itr] += 1`
  * under `omp atomic`) with the same result: integer adds commute. */
 __device__ __forceinline__ void ntsm_add_hits(const NtsmCountParams &p, long long slot, int lane)
 {
@@ -129,7 +130,6 @@ __device__ __forceinline__ void ntsm_add_hits(const NtsmCountParams &p, long lon
 	}
 	if (act) __hip_atomic_fetch_add(ntsm_count_ptr(p.keys, slot), p.sign, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
 template <int C, bool PER_READ>
 __global__ __launch_bounds__(kThreads, PER_READ ? 3 : 4) void ntsm_count_kernel(const NtsmCountParams p)
 {

@@ -11,6 +11,7 @@
 int main(int argc, char **argv)
 {
 	if (argc < 2) return 1;
+	if (getenv("CHUNK")) ntsm::GzStream::set_parallel_chunk((size_t) atol(getenv("CHUNK")));
 	std::vector<unsigned char> buf(4u << 20);
 	for (int a = 2; a < argc || a == 2; ++a) {
 		const int n = a < argc ? atoi(argv[a]) : 1;
