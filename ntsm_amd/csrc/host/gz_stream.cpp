@@ -168,6 +168,8 @@ void GzStream::produce()
 	Inflate inf;
 	const uint8_t *p = m_map, *const end = m_map + m_size;
 	std::unique_ptr<Parallel> par;
+	g_par_spliced = 0;
+	g_par_dropped = 0;
 	auto finish = [&](int status) {
 		if (par) { g_par_spliced = par->spliced; g_par_dropped = par->dropped; }
 		std::unique_ptr<Piece> e = blank();
@@ -379,49 +381,86 @@ const uint8_t *GzStream::produce_bgzf(const uint8_t *p, unsigned n_threads)
 	return resume;
 }
 
+/* Next piece in stream order, with what read() used to do as the bytes went by: CRC-32 and length of the member so far (a
+ * spliced chunk brings its own CRC: combined; BGZF groups were verified by their workers), the check at a member's end, the
+ * final status. */
+std::unique_ptr<GzStream::Piece> GzStream::pop()
+{
+	if (m_final) return nullptr;
+	std::unique_ptr<Piece> p;
+	{
+		std::unique_lock<std::mutex> lk(m_mu);
+		m_cv.wait(lk, [&]() { return !m_ready.empty() && m_ready.front()->ready; });
+		p = std::move(m_ready.front());
+		m_ready.pop_front();
+	}
+	m_cv.notify_all();
+	if (p->len && !p->checked) {
+		if (p->have_crc) m_crc = (uint32_t) crc32_combine(m_crc, p->crc, (z_off_t) p->len);
+		else m_crc = crc32_fast(m_crc, p->data.data(), p->len);
+		m_len += p->len;
+	}
+	if (p->member_end) {
+		if (m_crc != p->crc || (uint32_t) m_len != p->isize) m_final = -1;   /* zlib: incorrect data / length check */
+		m_crc = 0;
+		m_len = 0;
+	}
+	if (p->status && !m_final) m_final = p->status;
+	return p;
+}
+
+void GzStream::give_back(std::unique_ptr<Piece> p)
+{
+	if (!p) return;
+	std::lock_guard<std::mutex> lk(m_mu);
+	if (m_free.size() < 2 * kQueue) m_free.push_back(std::move(p));
+}
+
+std::unique_ptr<GzStream::Piece> GzStream::take()
+{
+	for (;;) {
+		std::unique_ptr<Piece> p = pop();
+		if (!p) return nullptr;
+		if (p->len) return p;
+		const bool last = m_final != 0;
+		give_back(std::move(p));
+		if (last) return nullptr;
+	}
+}
+
+void GzStream::unread(std::deque<std::unique_ptr<Piece>> pieces, size_t offset)
+{
+	if (m_cur) { give_back(std::move(m_cur)); m_cur.reset(); }
+	m_stash = std::move(pieces);
+	m_stashOff = offset;
+}
+
 int GzStream::read(void *dst, unsigned len)
 {
 	uint8_t *d = (uint8_t *) dst;
 	unsigned got = 0;
 	while (got < len) {
 		if (!m_cur) {
-			if (m_final) break;
-			std::unique_lock<std::mutex> lk(m_mu);
-			m_cv.wait(lk, [&]() { return !m_ready.empty() && m_ready.front()->ready; });
-			m_cur = std::move(m_ready.front());
-			m_ready.pop_front();
-			lk.unlock();
-			m_cv.notify_all();
-			m_off = 0;
+			if (!m_stash.empty()) {
+				m_cur = std::move(m_stash.front());
+				m_stash.pop_front();
+				m_off = m_stashOff;
+				m_stashOff = 0;
+			} else {
+				m_cur = pop();
+				if (!m_cur) break;
+				m_off = 0;
+			}
 		}
 		const size_t n = std::min<size_t>(len - got, m_cur->len - m_off);
 		if (n) {
 			memcpy(d + got, m_cur->data.data() + m_off, n);
-			if (m_cur->have_crc) {                               /* a spliced chunk: its CRC came with it, once for the whole piece */
-				if (m_off == 0) {
-					m_crc = (uint32_t) crc32_combine(m_crc, m_cur->crc, (z_off_t) m_cur->len);
-					m_len += m_cur->len;
-				}
-			} else if (!m_cur->checked) {
-				m_crc = crc32_fast(m_crc, d + got, n);
-				m_len += n;
-			}
 			m_off += n;
 			got += (unsigned) n;
 		}
-		if (m_off == m_cur->len) {
-			if (m_cur->member_end) {
-				if (m_crc != m_cur->crc || (uint32_t) m_len != m_cur->isize) m_final = -1;   /* zlib: incorrect data / length check */
-				m_crc = 0;
-				m_len = 0;
-			}
-			if (m_cur->status) m_final = m_cur->status;
-			{
-				std::lock_guard<std::mutex> lk(m_mu);
-				m_free.push_back(std::move(m_cur));
-			}
+		if (m_off >= m_cur->len) {
+			give_back(std::move(m_cur));
 			m_cur.reset();
-			if (m_final) break;
 		}
 	}
 	if (got) return (int) got;

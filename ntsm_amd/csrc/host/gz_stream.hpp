@@ -56,7 +56,6 @@ public:
 	int read(void *dst, unsigned len);
 	void close();
 
-private:
 	struct Piece {
 		std::vector<uint8_t> data;
 		size_t len = 0;
@@ -67,6 +66,18 @@ private:
 		uint32_t crc = 0, isize = 0;
 		int status = 0;                                /* after these bytes: 0 = more, 1 = end of data, -1 = error */
 	};
+	/* Piece-wise consumption (parallel_gz_fastq.hpp: several parsing threads instead of one read() loop).  take() returns the
+	 * next piece of text in stream order (len > 0), nullptr once the data has ended -- final_status() then says how: 1 = clean
+	 * end (or truncated file: every decodable byte was delivered, like gzread), -1 = invalid data / CRC / length.  Member
+	 * checks are made as the pieces pass, exactly as read() makes them.  One caller at a time (callers serialise).
+	 * give_back() recycles a piece's buffer; unread() puts pieces back IN FRONT of everything not yet taken, the first one
+	 * from byte `offset` on, for a following read() loop (the sequential reader after a parallel phase). */
+	std::unique_ptr<Piece> take();
+	int final_status() const { return m_final; }
+	void give_back(std::unique_ptr<Piece> p);
+	void unread(std::deque<std::unique_ptr<Piece>> pieces, size_t offset);
+
+private:
 	void produce();
 	struct Parallel;                                   /* gz_parallel.cpp: chunk workers of the parallel plain-gzip decoder */
 	friend struct Parallel;
@@ -83,6 +94,9 @@ private:
 	std::deque<std::unique_ptr<Piece>> m_ready, m_free;
 	bool m_stop = false;
 	/* reader side */
+	std::unique_ptr<Piece> pop();                      /* next piece of any kind with the member accounting applied; nullptr after the final one */
+	std::deque<std::unique_ptr<Piece>> m_stash;        /* unread(): consumed before anything else */
+	size_t m_stashOff = 0;
 	std::unique_ptr<Piece> m_cur;
 	size_t m_off = 0;
 	uint32_t m_crc = 0;

@@ -33,13 +33,26 @@ uint64_t SpecInflate::find(const uint8_t *base, const uint8_t *end, uint64_t fro
 		if ((x & 7u) != 4u) continue;                                         /* BFINAL = 0, BTYPE = 10b */
 		if (((x >> 3) & 31u) > 29u || ((x >> 8) & 31u) > 29u) continue;
 		const unsigned ncode = (unsigned) ((x >> 13) & 15u) + 4u;
-		/* precode lengths: 3 bits each from bit 17 of the candidate, up to 19 of them (bits 17 .. 73) */
-		unsigned __int128 z = ((((unsigned __int128) load64(p + 8)) << 64) | load64(p)) >> (sh + 17);
+		/* precode lengths: 3 bits each from bit 17 of the candidate, up to 19 of them (bits 17 .. 73).  x holds the first 13
+		 * (bits 17 .. 55): most false candidates are over-subscribed by then (a random length adds 16 of the 128 on average). */
 		unsigned kraft = 0, used = 0;
-		for (unsigned i = 0; i < ncode; ++i) {
-			const unsigned l = (unsigned) z & 7u;
-			z >>= 3;
-			if (l) { kraft += 128u >> l; ++used; }
+		{
+			uint64_t z = x >> 17;
+			const unsigned n13 = ncode < 13u ? ncode : 13u;
+			for (unsigned i = 0; i < n13; ++i) {
+				const unsigned l = (unsigned) z & 7u;
+				z >>= 3;
+				if (l) { kraft += 128u >> l; ++used; }
+			}
+			if (kraft > 128u) continue;
+			if (ncode > 13u) {
+				unsigned __int128 w = ((((unsigned __int128) load64(p + 8)) << 64) | load64(p)) >> (sh + 17 + 39);
+				for (unsigned i = 13; i < ncode; ++i) {
+					const unsigned l = (unsigned) w & 7u;
+					w >>= 3;
+					if (l) { kraft += 128u >> l; ++used; }
+				}
+			}
 		}
 		if (kraft != 128u || used < 2) continue;
 		reset_at(p, sh, end, 0);
@@ -202,49 +215,59 @@ Inflate::Status SpecInflate::run16(uint16_t *sym, size_t *out, size_t out_stop)
 }
 
 namespace {
-bool resolve_scalar(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out)
+/* out[i] = sym[i] < 256 ? sym[i] : window[sym[i] & 0x7FFF], through one 64 KiB table (literals map to themselves, markers to
+ * their window byte): FASTQ chunks are full of markers (every quality line is a copy of a copy ... of the window), so a
+ * branch per symbol would mispredict all the time */
+inline void table_run(const uint8_t *lut, const uint16_t *sym, size_t n, uint8_t *out)
 {
-	const uint16_t lowest = (uint16_t) (SpecInflate::kMarker | (SpecInflate::kWindow - valid));
-	bool ok = true;
-	for (size_t i = 0; i < n; ++i) {
-		const uint16_t s = sym[i];
-		if (s < 256) out[i] = (uint8_t) s;
-		else {
-			ok &= s >= lowest;
-			out[i] = window[s & 0x7FFFu];
-		}
+	size_t i = 0;
+	const size_t n8 = n & ~(size_t) 7;
+	for (; i < n8; i += 8) {
+		const uint64_t v = (uint64_t) lut[sym[i]] | ((uint64_t) lut[sym[i + 1]] << 8) | ((uint64_t) lut[sym[i + 2]] << 16) | ((uint64_t) lut[sym[i + 3]] << 24) |
+			((uint64_t) lut[sym[i + 4]] << 32) | ((uint64_t) lut[sym[i + 5]] << 40) | ((uint64_t) lut[sym[i + 6]] << 48) | ((uint64_t) lut[sym[i + 7]] << 56);
+		memcpy(out + i, &v, 8);
 	}
-	return ok;
+	for (; i < n; ++i) out[i] = lut[sym[i]];
 }
 #if defined(__x86_64__)
-__attribute__((target("avx2"))) bool resolve_avx2(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out)
+__attribute__((target("avx2"))) void resolve_avx2(const uint8_t *lut, const uint16_t *sym, size_t n, uint8_t *out)
 {
+	/* groups of 32 literals go through a pack, everything else through the table */
 	const __m256i hi = _mm256_set1_epi16((short) 0xFF00);
-	bool ok = true;
 	size_t i = 0;
 	for (; i + 32 <= n; i += 32) {
 		const __m256i a = _mm256_loadu_si256((const __m256i *) (sym + i));
 		const __m256i b = _mm256_loadu_si256((const __m256i *) (sym + i + 16));
-		if (_mm256_testz_si256(_mm256_or_si256(a, b), hi)) {       /* 32 literals */
-			const __m256i p = _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8);
-			_mm256_storeu_si256((__m256i *) (out + i), p);
-		} else {
-			ok &= resolve_scalar(sym + i, 32, window, valid, out + i);
-		}
+		if (_mm256_testz_si256(_mm256_or_si256(a, b), hi))
+			_mm256_storeu_si256((__m256i *) (out + i), _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8));
+		else
+			table_run(lut, sym + i, 32, out + i);
 	}
-	ok &= resolve_scalar(sym + i, n - i, window, valid, out + i);
-	return ok;
+	table_run(lut, sym + i, n - i, out + i);
 }
 #endif
 } // namespace
 
 bool SpecInflate::resolve(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out)
 {
+	static thread_local uint8_t lut[65536];
+	static thread_local bool literals_done = false;
+	if (!literals_done) {
+		for (int i = 0; i < 65536; ++i) lut[i] = (uint8_t) i;    /* values 256 .. 32767 never occur */
+		literals_done = true;
+	}
+	memcpy(lut + kMarker, window, kWindow);
 #if defined(__x86_64__)
 	static const bool avx2 = __builtin_cpu_supports("avx2");
-	if (avx2) return resolve_avx2(sym, n, window, valid, out);
+	if (avx2) resolve_avx2(lut, sym, n, out);
+	else
 #endif
-	return resolve_scalar(sym, n, window, valid, out);
+		table_run(lut, sym, n, out);
+	if (valid < kWindow) {                                      /* a marker in front of the member's first byte: invalid distance */
+		const uint16_t lowest = (uint16_t) (kMarker | (kWindow - valid));
+		for (size_t j = 0; j < n; ++j) if (sym[j] >= 256 && sym[j] < lowest) return false;
+	}
+	return true;
 }
 
 } // namespace ntsm

@@ -178,7 +178,7 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
     import subprocess
     exe = str(tmp_path / "host_sanitize")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
-    srcs = [os.path.join(ROOT, "tools", "host_sanitize.cpp")] + [os.path.join(host, f) for f in ("seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "gz_stream.cpp", "crc32_fast.cpp")]
+    srcs = [os.path.join(ROOT, "tools", "host_sanitize.cpp")] + [os.path.join(host, f) for f in ("seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "inflate_spec.cpp", "gz_stream.cpp", "gz_parallel.cpp", "crc32_fast.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     reads = [p for p in INPUTS if not os.path.basename(p).startswith("sites")]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
@@ -291,7 +291,7 @@ def test_block_parallel_ingest_under_tsan(nt, tmp_path):
     exe = str(tmp_path / "parallel_tsan")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
     srcs = [os.path.join(ROOT, "tools", "parallel_tsan.cpp")] + [os.path.join(host, f) for f in
-            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "gz_stream.cpp", "crc32_fast.cpp", "pack2.cpp")]
+            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "inflate_spec.cpp", "gz_stream.cpp", "gz_parallel.cpp", "crc32_fast.cpp", "pack2.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
     fq = str(tmp_path / "t.fq")
@@ -391,6 +391,116 @@ def test_gzip_decoder_matches_zlib(nt, tmp_path):
         assert gunzip(p)[1] == -1 and gunzip(p, 1)[1] == -1
 
 
+def test_parallel_gzip_decoder_matches_zlib(nt, tmp_path):
+    """The chunk-parallel decoder for ONE ordinary gzip stream (gz_parallel.cpp: speculative 16-bit decoding from block starts
+    found by trial, spliced in by the in-order decoder) against zlib's gzread: every compression level / strategy / window of
+    the sequential test's corpus with chunks small enough that each file is cut many times, sync / full flush blocks,
+    concatenated members (also tiny and empty ones), trailing garbage, a stored-block-only file (no chunk ever starts: all in
+    order), CRC / ISIZE damage, 51 truncation points and 160 bit flips with the same bytes / verdict as gzread."""
+    import random
+    import zlib
+    from ntsm_amd.capi import gunzip, gunzip_parallel_chunk, gunzip_parallel_stats
+    rng = random.Random(2)
+    p = str(tmp_path / "t.gz")
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(150)),
+                                          bytes(rng.choice(b"FFFF:,#") for _ in range(150))) for i in range(9000))
+    payloads = [b"ACGT" * 200000, bytes(rng.getrandbits(8) for _ in range(300000)), fq, bytes(rng.choice(b"ab") for _ in range(400000)),
+                b"\x00" * 2500000, bytes((i * 7 + (i >> 8)) & 0xFF for i in range(1 << 20))]
+    try:
+        n = spliced_total = 0
+        for pi, data in enumerate(payloads):
+            for level in (0, 1, 6, 9):
+                for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                    for wbits, memlevel in ((15, 8), (9, 1), (12, 9)):
+                        if (wbits, memlevel) != (15, 8) and not (pi in (2, 3) and level == 6):
+                            continue
+                        blob = _gz_member(data, level, strategy, wbits, memlevel)
+                        open(p, "wb").write(blob)
+                        for chunk in (4096, 50000):
+                            gunzip_parallel_chunk(chunk)
+                            got, rc = gunzip(p, 3, 1 << 16)
+                            assert rc == 0 and got == data, (pi, level, strategy, wbits, memlevel, chunk, rc, len(got), len(data))
+                            st = gunzip_parallel_stats()
+                            spliced_total += st[0]
+                            if level == 0 or strategy == zlib.Z_FIXED:
+                                assert st[0] == 0                      # stored / fixed blocks only: nothing for a chunk to start at
+                            n += 1
+        assert n > 200 and spliced_total > 1000
+        gunzip_parallel_chunk(8192)
+        data = b"".join(b"@r%d\nACGTTGCA%d\n+\nFFFFFFFF\n" % (i, i) for i in range(60000))
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        parts = []
+        for i in range(0, len(data), 70000):
+            parts += [co.compress(data[i:i + 70000]), co.flush(zlib.Z_SYNC_FLUSH if (i // 70000) % 2 else zlib.Z_FULL_FLUSH)]
+        open(p, "wb").write(b"".join(parts) + co.flush())
+        assert gunzip(p, 4) == (data, 0) and gunzip_parallel_stats()[0] > 5
+        multi = _gz_member(data[:700000]) + _gz_member(b"") + _gz_member(data[700000:1500000], 1) + _gz_member(data[:10], 0) + _gz_member(data[1500000:], 9) + _gz_member(b"x")
+        open(p, "wb").write(multi)
+        assert gunzip(p, 4) == (data + data[:10] + b"x" if False else data[:700000] + data[700000:1500000] + data[:10] + data[1500000:] + b"x", 0)
+        assert gunzip_parallel_stats()[0] > 5
+        open(p, "wb").write(multi + b"garbage after the last member")
+        assert gunzip(p, 4) == gunzip(p, 1)
+        good = _gz_member(data)
+        for blob in (good[:-8] + bytes([good[-8] ^ 1]) + good[-7:], good[:-4] + bytes([good[-4] ^ 1]) + good[-3:]):   # CRC, ISIZE
+            open(p, "wb").write(blob)
+            got, rc = gunzip(p, 4)
+            assert rc == -1 and gunzip(p, 1)[1] == -1 and got == data
+        for cut in [len(good) - k for k in (1, 4, 7, 8, 9, 20)] + [rng.randrange(11, len(good)) for _ in range(40)] + [10, 11, 12, 3, 9]:
+            open(p, "wb").write(good[:cut])
+            got, rc = gunzip(p, 4)
+            ref, rrc = gunzip(p, 1)
+            assert rc == rrc == 0 and got == ref, ("truncated at", cut, rc, rrc, len(got), len(ref))
+        for _ in range(160):                                            # single bit flips: same verdict as zlib, same bytes when it accepts
+            b = bytearray(good)
+            i = rng.randrange(10, len(good) - 8)
+            b[i] ^= 1 << rng.randrange(8)
+            open(p, "wb").write(bytes(b))
+            got, rc = gunzip(p, 4)
+            ref, rrc = gunzip(p, 1)
+            assert rc == rrc and (rc != 0 or got == ref), ("flip", i, rc, rrc)
+        # a real-sized FASTQ at the default chunk size
+        gunzip_parallel_chunk(0)
+        s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=9, p_embed=0.2)
+        fqp = str(tmp_path / "big.fq")
+        s.write_fastq(fqp, 0, 150000, threads=4)
+        raw = open(fqp, "rb").read()
+        open(p, "wb").write(_gz_member(raw, 6))
+        assert gunzip(p, 4, 1 << 20) == (raw, 0) and gunzip_parallel_stats()[0] >= 2
+    finally:
+        gunzip_parallel_chunk(0)
+
+
+def test_parallel_gzip_under_tsan_and_asan(nt, tmp_path):
+    """Producer / chunk workers / reader of the parallel plain-gzip path under ThreadSanitizer, and its speculative decoder on
+    good, truncated and damaged streams under AddressSanitizer + UBSan."""
+    import random
+    import subprocess
+    host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
+    srcs = [os.path.join(ROOT, "tools", "gunzip_sanitize.cpp")] + [os.path.join(host, f) for f in ("gz_stream.cpp", "gz_parallel.cpp", "inflate.cpp", "inflate_spec.cpp", "crc32_fast.cpp")]
+    rng = random.Random(9)
+    data = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(100)), bytes(rng.choice(b"FFF:,") for _ in range(100))) for i in range(20000))
+    good = _gz_member(data, 6)
+    files = []
+    blobs = [("good", good), ("trunc", good[:len(good) * 2 // 3]), ("multi", good + _gz_member(data[:5000], 1) + good)]
+    for j in range(12):
+        b = bytearray(good)
+        for _ in range(1 + j % 3):
+            b[rng.randrange(10, len(b))] ^= 1 << rng.randrange(8)
+        blobs.append(("bad%d" % j, bytes(b)))
+    for name, blob in blobs:
+        path = str(tmp_path / (name + ".gz"))
+        open(path, "wb").write(blob)
+        files.append(path)
+    for san, extra in (("thread", []), ("address,undefined", ["-fno-sanitize-recover=all"])):
+        exe = str(tmp_path / ("gunzip_" + san.split(",")[0]))
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san] + extra + ["-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
+        p = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", NTSM_DECODER_THREADS="5", NTSM_PARALLEL_CHUNK="20000"))
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        out = p.stdout.split()
+        assert out[0:2] == [b"%d" % len(data), b"0"] and out[3] == b"0" and out[4:6] == [b"%d" % (2 * len(data) + 5000), b"0"], out[:8]
+
+
 def test_gzip_reader_paths_agree(nt, tmp_path, monkeypatch):
     """SeqReader over the decoder thread == SeqReader over zlib (NTSM_ZLIB_ONLY) on every gzip input of the
     golden set and on a multi-member FASTQ."""
@@ -421,7 +531,7 @@ def test_bgzf_parallel_inflate_under_tsan(nt, tmp_path):
     import subprocess
     exe = str(tmp_path / "gunzip_tsan")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
-    srcs = [os.path.join(ROOT, "tools", "gunzip_sanitize.cpp")] + [os.path.join(host, f) for f in ("gz_stream.cpp", "inflate.cpp", "crc32_fast.cpp")]
+    srcs = [os.path.join(ROOT, "tools", "gunzip_sanitize.cpp")] + [os.path.join(host, f) for f in ("gz_stream.cpp", "gz_parallel.cpp", "inflate.cpp", "inflate_spec.cpp", "crc32_fast.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     rng = random.Random(5)
     data = bytes(rng.choice(b"ACGTN\n@+F") for _ in range(3_000_000))
@@ -447,7 +557,7 @@ def test_gzip_decoder_corrupt_streams_under_asan(nt, tmp_path):
     import zlib
     exe = str(tmp_path / "gunzip_sanitize")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
-    srcs = [os.path.join(ROOT, "tools", "gunzip_sanitize.cpp")] + [os.path.join(host, f) for f in ("gz_stream.cpp", "inflate.cpp", "crc32_fast.cpp")]
+    srcs = [os.path.join(ROOT, "tools", "gunzip_sanitize.cpp")] + [os.path.join(host, f) for f in ("gz_stream.cpp", "gz_parallel.cpp", "inflate.cpp", "inflate_spec.cpp", "crc32_fast.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     rng = random.Random(7)
     text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(100)), b"F" * 100) for i in range(3000))

@@ -9,7 +9,8 @@
 int main(int argc, char **argv)
 {
 	std::vector<unsigned char> buf(1 << 16);
-	if (const char *t = getenv("NTSM_DECODER_THREADS")) ntsm::GzStream::set_decoder_threads((unsigned) atoi(t));   /* BGZF: block-parallel */
+	if (const char *t = getenv("NTSM_DECODER_THREADS")) ntsm::GzStream::set_decoder_threads((unsigned) atoi(t));   /* BGZF: block-parallel; plain gzip: chunk-parallel */
+	if (const char *c = getenv("NTSM_PARALLEL_CHUNK")) ntsm::GzStream::set_parallel_chunk((size_t) atol(c));     /* compressed bytes per chunk of the latter */
 	for (int i = 1; i < argc; ++i) {
 		ntsm::GzStream gz;
 		if (!gz.open(argv[i])) { printf("open-failed\n"); continue; }
