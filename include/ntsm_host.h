@@ -51,6 +51,13 @@ int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out
  * (0 = the default 2 MiB; files shorter than two chunks are decoded in order).  stats, if not NULL, receives what the last
  * ntsm_host_gunzip call with engine >= 2 did: [0] chunks spliced in, [1] chunks dropped (no block start found in their
  * range, start not confirmed by the in-order decoder, or decoding failed). */
+/* Test hook for the parallel gzip ingest (parallel_gz_fastq.hpp over gz_stream.hpp): n_decoders decoder threads inflate
+ * `path`, n_parsers threads parse the pieces (sinks of sink_bytes each), the sequential reader finishes what the parallel
+ * phase left.  Reads come back piece by piece; INSIDE a piece the records carried over from the previous piece may stand
+ * before or between the piece's own (the counting path does not depend on read order).  Returns 0, 1 if the file is not
+ * gzip, -1 if it cannot be opened.  *n_parallel = records committed by the parallel phase. */
+int ntsm_host_flatten_parallel_gz(const char *path, unsigned n_decoders, unsigned n_parsers, uint64_t sink_bytes, uint8_t **bases,
+		uint64_t *n_bytes, uint64_t **read_end, uint64_t *n_reads, uint64_t *n_pieces, uint64_t *n_parallel, int *final_status);
 void ntsm_host_gunzip_parallel_chunk(uint64_t bytes);
 void ntsm_host_gunzip_parallel_stats(uint64_t stats[2]);
 /* Block-parallel variant for plain 4-line FASTQ (ntsm_amd/csrc/host/parallel_fastq.hpp), for tests: the records

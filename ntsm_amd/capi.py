@@ -101,6 +101,7 @@ _sig(HO, "ntsm_host_max_hits", C.c_uint64, [C.c_uint64, C.c_double])
 _sig(HO, "ntsm_host_flatten", C.c_int, [C.c_char_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, C.POINTER(C.c_int)])
 _sig(HO, "ntsm_host_free", None, [C.c_void_p])
 _sig(HO, "ntsm_host_gunzip", C.c_int, [C.c_char_p, C.c_int, C.c_uint, C.POINTER(u8p), u64p])
+_sig(HO, "ntsm_host_flatten_parallel_gz", C.c_int, [C.c_char_p, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, C.POINTER(C.c_int)])
 _sig(HO, "ntsm_host_gunzip_parallel_chunk", None, [C.c_uint64])
 _sig(HO, "ntsm_host_gunzip_parallel_stats", None, [u64p])
 _sig(HO, "ntsm_host_flatten_parallel", C.c_int, [C.c_char_p, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, u64p])
@@ -240,6 +241,24 @@ def flatten_file_parallel(path, n_threads=4, block_bytes=1 << 20):
     HO.ntsm_host_free(b)
     HO.ntsm_host_free(e)
     return bases, ends, dict(blocks=int(nblk.value), parallel_records=int(npar.value), resume=int(res.value))
+
+
+def flatten_file_parallel_gz(path, n_decoders=4, n_parsers=4, sink_bytes=1 << 20):
+    """Parallel gzip ingest (decoder pool + piece-parallel parse + sequential rest); None when the file is not gzip.
+    Returns (bases, read_end, info); reads are in file order piece by piece, not necessarily inside a piece."""
+    b, e = u8p(), u64p()
+    nb, nr, npc, npar, st = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+    rc = HO.ntsm_host_flatten_parallel_gz(os.fsencode(path), n_decoders, n_parsers, sink_bytes, C.byref(b), C.byref(nb), C.byref(e), C.byref(nr),
+                                          C.byref(npc), C.byref(npar), C.byref(st))
+    if rc < 0:
+        raise NtsmError("flatten_parallel_gz(%s) failed: %d" % (path, rc))
+    if rc == 1:
+        return None
+    bases = np.ctypeslib.as_array(b, shape=(nb.value,)).copy() if nb.value else np.zeros(0, np.uint8)
+    ends = np.ctypeslib.as_array(e, shape=(nr.value,)).copy() if nr.value else np.zeros(0, np.uint64)
+    HO.ntsm_host_free(b)
+    HO.ntsm_host_free(e)
+    return bases, ends, dict(pieces=int(npc.value), parallel_records=int(npar.value), status=int(st.value))
 
 
 def flatten_reads(reads):

@@ -9,10 +9,12 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
+#include <sys/stat.h>
 
 #include "gz_stream.hpp"
 #include "pack2.hpp"
 #include "parallel_fastq.hpp"
+#include "parallel_gz_fastq.hpp"
 #include <chrono>
 #include "report.hpp"
 #include "seq_reader.hpp"
@@ -133,6 +135,17 @@ void Feeder::feedFile(const std::string &fn, uint64_t offset)
 		 * verbosity, after the read has been processed and the next one fetched).  The totals have to be those after exactly
 		 * that many reads, so the batch is submitted and waited for here -- a debugging verbosity, run on one thread. */
 		if (m_opt.verbose > 2 && !m_useLane && (++m_totalReads % 1000000) == 0) progressLine();
+	}
+}
+
+void Feeder::feedStream(std::unique_ptr<GzStream> gz)
+{
+	SeqReader rd;
+	if (!rd.open_stream(std::move(gz))) return;
+	int64_t l = rd.next();
+	while (l >= 0 && !m_earlyTerm) {
+		feedRead(rd.seq_data(), (uint64_t) l);
+		l = rd.next();
 	}
 }
 
@@ -365,6 +378,49 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 		if (m_opt.phase_times)
 			std::cerr << "[phase] " << fn << ": lanes " << std::chrono::duration<double>(tp1 - tp0).count() << " s, parse+count "
 			          << std::chrono::duration<double>(tp2 - tp1).count() << " s (" << r.records << " records in parallel)" << std::endl;
+	}
+	/* A big gzip file (plain or BGZF) is inflated by a pool of decoder threads (gz_stream.hpp) and the text is parsed piece-
+	 * parallel by the same feeders (parallel_gz_fastq.hpp); small ones and NTSM_ZLIB_ONLY stay one thread per file. */
+	if (!getenv("NTSM_ZLIB_ONLY")) {
+		std::vector<std::string> small;
+		for (const std::string &fn : rest) {
+			struct stat st;
+			if (!(stat(fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (uint64_t) st.st_size >= m_opt.gz_parallel_min_bytes && GzStream::is_gzip(fn))) { small.push_back(fn); continue; }
+			const auto tp0 = std::chrono::steady_clock::now();
+			const size_t n_par = std::min<size_t>(want, 16);
+			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+			const unsigned n_dec = (unsigned) std::min<size_t>(std::min<size_t>(64, hw), 2 * want);
+			GzStream::set_decoder_threads(n_dec);
+			std::unique_ptr<GzStream> gz(new GzStream());
+			if (!gz->open(fn)) { small.push_back(fn); continue; }
+			if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "parallel gzip: " << n_dec << " decoder threads, " << n_par << " parsing threads" << std::endl;
+			{
+				std::vector<std::thread> mk;
+				for (size_t t = 0; t < n_par; ++t) mk.emplace_back([this, t]() { (void) feederFor(t); });
+				for (auto &th : mk) th.join();
+			}
+			std::vector<Feeder *> sinks;
+			for (size_t t = 0; t < n_par; ++t) sinks.push_back(&feederFor(t));
+			const auto tp1 = std::chrono::steady_clock::now();
+			ParallelGzFastq pg(gz.get());
+			const ParallelGzFastq::Result r = pg.run(sinks);
+			const auto tp2 = std::chrono::steady_clock::now();
+			if (!r.complete) {                                      /* what is left is not plain 4-line FASTQ (or the last record has no newline) */
+				if (m_opt.verbose) std::cerr << "parallel gzip: sequential after " << r.records << " records" << std::endl;
+				feederFor(0).feedStream(std::move(gz));
+				feederFor(0).flush();
+			}
+			if (m_opt.phase_times) {
+				uint64_t ps[2];
+				GzStream::last_parallel_stats(ps);
+				std::cerr << "[phase] " << fn << ": lanes " << std::chrono::duration<double>(tp1 - tp0).count() << " s, inflate+parse+count "
+				          << std::chrono::duration<double>(tp2 - tp1).count() << " s (" << r.records << " records in " << r.pieces << " pieces in parallel, "
+				          << ps[0] << " chunks spliced, " << ps[1] << " dropped), rest "
+				          << std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count() << " s" << std::endl;
+			}
+		}
+		rest.swap(small);
+		GzStream::set_decoder_threads((unsigned) std::max<size_t>(1, m_opt.threads / std::max<size_t>(1, std::min(want, std::max<size_t>(1, rest.size())))));
 	}
 	if (!rest.empty()) {
 		const size_t n_threads = std::min<size_t>(want, rest.size());

@@ -36,6 +36,9 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	/* Producer lanes send 2-bit codes + a validity bit per position (3/8 byte instead of 1 over PCIe; pack2.hpp) and the
 	 * device unpacks them.  NTSM_NO_PACK=1 sends the raw bytes instead (same counts: A/B of the two ingest forms). */
 	bool pack = true;
+	/* gzip inputs of at least this many (compressed) bytes take the parallel route with -t N: decoder pool + piece-parallel
+	 * parsing (gz_stream.hpp, parallel_gz_fastq.hpp); smaller ones are read one thread per file */
+	uint64_t gz_parallel_min_bytes = 8ull << 20;
 };
 
 /* The staging batch one host thread is filling for a GPU context: the context's own slots (single-threaded and
@@ -48,6 +51,8 @@ public:
 	Feeder &operator=(const Feeder &) = delete;
 	/* Count every record of one file (src/FingerPrint.hpp:49-81); stops early once the -m threshold tripped. */
 	void feedFile(const std::string &path, uint64_t offset = 0);
+	/* the same on an open gzip stream positioned at a record boundary (what a parallel phase left, parallel_gz_fastq.hpp) */
+	void feedStream(std::unique_ptr<class GzStream> gz);
 	/* One read (insertCount(seq.s, seq.l), src/FingerPrint.hpp:89-103): append to the staging batch. */
 	void feedRead(const char *seq, uint64_t len);
 	void flush();

@@ -18,7 +18,7 @@
 namespace ntsm {
 
 namespace {
-constexpr size_t kPiece = 1u << 20, kWindow = 32768, kSlack = 512, kQueue = 8;
+constexpr size_t kPiece = 1u << 20, kWindow = 32768, kSlack = 512, kQueue = 32;
 inline uint32_t le32(const uint8_t *p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24); }
 
 /* gzip member header (RFC 1952 2.3): returns the offset of the deflate data, 0 on invalid data, SIZE_MAX when the
@@ -111,6 +111,8 @@ bool GzStream::open(const std::string &path)
 	m_off = 0;
 	m_crc = 0;
 	m_len = 0;
+	m_nThreads = g_decoder_threads;                        /* as set when the stream was opened */
+	m_chunkBytes = g_parallel_chunk;
 	m_thread = std::thread([this]() { produce(); });
 	return true;
 }
@@ -177,7 +179,7 @@ void GzStream::produce()
 		push(std::move(e));
 	};
 	bool first = true;
-	const unsigned n_threads = g_decoder_threads;
+	const unsigned n_threads = m_nThreads;
 	if (n_threads > 1 && bgzf_member_size(p, (size_t) (end - p))) {
 		const uint8_t *q = produce_bgzf(p, n_threads);
 		if (!q) return;
@@ -185,7 +187,7 @@ void GzStream::produce()
 		p = q;
 	}
 	/* one long deflate stream (everything that is not BGZF): chunk workers decode ahead, this thread splices (gz_parallel.hpp) */
-	const size_t chunk = g_parallel_chunk;
+	const size_t chunk = m_chunkBytes;
 	if (n_threads > 1 && (size_t) (end - p) >= 2 * chunk) par.reset(new Parallel(this, n_threads, chunk));
 	for (;;) {
 		/* member header (the first one was recognised by its magic; later ones: anything else is trailing garbage) */
@@ -242,8 +244,11 @@ void GzStream::produce()
 					pc->have_crc = true;
 					pc->ready = false;
 					Piece *raw = pc.get();
-					par->resolve_async(std::move(c), win, raw);    /* copies the window; fills raw->data, raw->crc, sets ready */
+					/* queued for the reader first (not ready: it waits), handed to the workers second: a reader that has gone
+					 * away (push refuses, the piece dies here) must never leave a worker writing into a freed piece.  Once
+					 * queued, the piece lives until close() has joined this thread and, through it, the workers. */
 					if (!push(std::move(pc))) return;
+					par->resolve_async(std::move(c), win, raw);    /* copies the window; fills raw->data, raw->crc, sets ready */
 				}
 				memcpy(work.data(), next_win, kWindow);
 				out = sent = kWindow;

@@ -93,6 +93,8 @@ private:
 	std::condition_variable m_cv;
 	std::deque<std::unique_ptr<Piece>> m_ready, m_free;
 	bool m_stop = false;
+	unsigned m_nThreads = 1;                           /* decoder threads / chunk size of this stream (the process-wide settings at open()) */
+	size_t m_chunkBytes = 2u << 20;
 	/* reader side */
 	std::unique_ptr<Piece> pop();                      /* next piece of any kind with the member accounting applied; nullptr after the final one */
 	std::deque<std::unique_ptr<Piece>> m_stash;        /* unread(): consumed before anything else */

@@ -11,6 +11,7 @@
 #include "gz_stream.hpp"
 #include "pack2.hpp"
 #include "parallel_fastq.hpp"
+#include "parallel_gz_fastq.hpp"
 #include "report.hpp"
 #include "seq_reader.hpp"
 #include "site_set.hpp"
@@ -179,6 +180,62 @@ int ntsm_host_flatten_parallel(const char *path, unsigned n_threads, uint64_t bl
 	memcpy(*read_end, e.data(), e.size() * sizeof(uint64_t));
 	*n_reads = e.size();
 	if (n_blocks) *n_blocks = pf.n_blocks();
+	return 0;
+}
+
+int ntsm_host_flatten_parallel_gz(const char *path, unsigned n_decoders, unsigned n_parsers, uint64_t sink_bytes, uint8_t **bases,
+		uint64_t *n_bytes, uint64_t **read_end, uint64_t *n_reads, uint64_t *n_pieces, uint64_t *n_parallel, int *final_status)
+{
+	if (!ntsm::GzStream::is_gzip(path)) return 1;
+	ntsm::GzStream::set_decoder_threads(n_decoders ? n_decoders : 1);
+	std::unique_ptr<ntsm::GzStream> gz(new ntsm::GzStream());
+	const bool opened = gz->open(path);
+	ntsm::GzStream::set_decoder_threads(1);
+	if (!opened) return -1;
+	if (n_parsers == 0) n_parsers = 1;
+	std::vector<CollectSink> sinks(n_parsers);
+	std::vector<CollectSink *> ptrs;
+	for (auto &s : sinks) { s.cap = sink_bytes ? sink_bytes : (1u << 20); ptrs.push_back(&s); }
+	ntsm::ParallelGzFastq pg(gz.get());
+	const ntsm::ParallelGzFastq::Result r = pg.run(ptrs);
+	std::vector<const CollectSink::Chunk *> order;
+	for (auto &s : sinks) {
+		if (!s.lens.empty()) return -2;                                             /* staged but never committed nor dropped */
+		for (auto &c : s.out) order.push_back(&c);
+	}
+	/* the chunks of one piece come from one thread; the bridge records of a piece are fed before or between its own records,
+	 * so inside a piece the order is not the file's -- callers compare as multisets per file or sort (counts do not depend on
+	 * the order of the reads) */
+	std::stable_sort(order.begin(), order.end(), [](const CollectSink::Chunk *a, const CollectSink::Chunk *b) { return a->block < b->block; });
+	std::vector<uint8_t> b;
+	std::vector<uint64_t> e;
+	for (const CollectSink::Chunk *c : order) {
+		uint64_t off = 0;
+		for (uint64_t len : c->lens) {
+			b.insert(b.end(), c->bases.begin() + (long) off, c->bases.begin() + (long) (off + len + 1));
+			e.push_back(b.size() - 1);
+			off += len + 1;
+		}
+	}
+	if (n_parallel) *n_parallel = e.size();
+	if (e.size() != r.records) return -2;
+	if (!r.complete) {                                                              /* the sequential reader takes over on the same stream */
+		ntsm::SeqReader rd;
+		if (!rd.open_stream(std::move(gz))) return -1;
+		for (int64_t l = rd.next(); l >= 0; l = rd.next()) {
+			b.insert(b.end(), rd.seq_data(), rd.seq_data() + l);
+			e.push_back(b.size());
+			b.push_back('N');
+		}
+	}
+	*bases = (uint8_t *) malloc(b.size() + 16);
+	memcpy(*bases, b.data(), b.size());
+	*n_bytes = b.size();
+	*read_end = (uint64_t *) malloc((e.size() + 1) * sizeof(uint64_t));
+	memcpy(*read_end, e.data(), e.size() * sizeof(uint64_t));
+	*n_reads = e.size();
+	if (n_pieces) *n_pieces = r.pieces;
+	if (final_status) *final_status = r.status;
 	return 0;
 }
 

@@ -250,12 +250,8 @@ __attribute__((target("avx2"))) void resolve_avx2(const uint8_t *lut, const uint
 
 bool SpecInflate::resolve(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out)
 {
-	static thread_local uint8_t lut[65536];
-	static thread_local bool literals_done = false;
-	if (!literals_done) {
-		for (int i = 0; i < 65536; ++i) lut[i] = (uint8_t) i;    /* values 256 .. 32767 never occur */
-		literals_done = true;
-	}
+	uint8_t lut[65536];                                         /* on the caller's stack: 0 .. 255 and 32768 .. 65535 are the only entries ever read */
+	for (int i = 0; i < 256; ++i) lut[i] = (uint8_t) i;
 	memcpy(lut + kMarker, window, kWindow);
 #if defined(__x86_64__)
 	static const bool avx2 = __builtin_cpu_supports("avx2");

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "fingerprint.hpp"
+#include "gz_stream.hpp"
 
 #define PROGRAM "ntsmCount"
 
@@ -145,6 +146,8 @@ int main(int argc, char *argv[])
 	if (const char *bb = getenv("NTSM_BATCH_BYTES")) opt.batch_bytes = strtoull(bb, nullptr, 10);   /* staging slot size */
 	if (getenv("NTSM_NO_PACK")) opt.pack = false;                                                  /* lanes send raw bytes instead of 2-bit codes + validity */
 	if (const char *pb = getenv("NTSM_BLOCK_BYTES")) opt.block_bytes = strtoull(pb, nullptr, 10);   /* block-parallel ingest block size */
+	if (const char *gm = getenv("NTSM_GZ_PARALLEL_MIN")) opt.gz_parallel_min_bytes = strtoull(gm, nullptr, 10);   /* smallest gzip file that takes the decoder pool + piece-parallel parse (-t N) */
+	if (const char *gc = getenv("NTSM_GZ_CHUNK")) ntsm::GzStream::set_parallel_chunk(strtoull(gc, nullptr, 10));  /* compressed bytes per chunk of the parallel gzip decoder */
 	const auto t0 = std::chrono::steady_clock::now();
 	const bool phases = opt.phase_times = getenv("NTSM_PHASE_TIMES") != nullptr;
 	if (phases) {                                          /* time between exec and main: loader + static initialisers of the HIP runtime */

@@ -88,10 +88,12 @@ public:
 		return r;
 	}
 
+	/* one strict record at p: returns one past its quality newline and the sequence, or nullptr (also used by
+	 * parallel_gz_fastq.hpp) */
+	static const char *strict_record(const char *p, const char *e, const char **seq, uint64_t *len);
+
 private:
 	static constexpr uint64_t kNone = ~0ull;
-	/* one strict record at p: returns one past its quality newline and the sequence, or nullptr */
-	static const char *strict_record(const char *p, const char *e, const char **seq, uint64_t *len);
 	/* offset of the first plausible record start in [lo, hi), kNone if there is none */
 	uint64_t find_start(uint64_t lo, uint64_t hi) const;
 	/* ordered commit: wait for block b-1, then true iff no earlier block failed and b-1 ended at `first` (first ==

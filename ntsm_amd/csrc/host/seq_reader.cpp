@@ -25,6 +25,18 @@ bool SeqReader::open(const std::string &path, uint64_t offset)
 	return true;
 }
 
+bool SeqReader::open_stream(std::unique_ptr<GzStream> gz)
+{
+	close();
+	if (!gz) return false;
+	gz_ = std::move(gz);
+	buf_.resize(kBuf);
+	beg_ = end_ = 0;
+	eof_ = false;
+	pending_ = 0;
+	return true;
+}
+
 int SeqReader::source_read(void *dst, unsigned len)
 {
 	return gz_ ? gz_->read(dst, len) : gzread(f_, dst, len);

@@ -36,6 +36,9 @@ public:
 
 	/* offset: start reading at this byte of the (uncompressed) stream; it must be a record boundary */
 	bool open(const std::string &path, uint64_t offset = 0);
+	/* continue on an open gzip stream (after the parallel phase of parallel_gz_fastq.hpp handed back what it did not parse:
+	 * the stream is positioned at a record boundary) */
+	bool open_stream(std::unique_ptr<GzStream> gz);
 	void close();
 	/* Next record: returns the sequence length (>= 0), -1 at end of file, -2 on a truncated
 	 * quality block, -3 on a stream error.  seq()/name() are valid until the next call. */

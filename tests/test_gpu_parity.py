@@ -892,6 +892,41 @@ def test_cli_threads_over_files(nt, tmp_path):
     assert p.returncode == 0 and p.stdout == open(os.path.join(G, "expected", c["stdout"]), "rb").read()
 
 
+def test_cli_parallel_gzip_ingest(nt, tmp_path):
+    """`reads.fq.gz` with -t N: the decoder pool inflates ONE ordinary gzip stream in parallel and the feeders parse the text
+    piece-parallel (gz_stream.hpp, parallel_gz_fastq.hpp); counts.txt and the summary are the single-thread bytes -- for a
+    strict file, a file with a wrapped record in the middle (sequential from there), several members, BGZF, a truncated file
+    and one with a damaged CRC, with chunks from 20 KB to the default."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.4, sites_path=str(tmp_path / "s.fa"))
+    fq = str(tmp_path / "t.fq")
+    s.write_fastq(fq, 0, 120000)
+    raw = open(fq, "rb").read()
+    lines = raw.split(b"\n")
+    lines[200001] = lines[200001][:50] + b"\n" + lines[200001][50:]
+    import zlib
+
+    def member(data, level=6):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return co.compress(data) + co.flush()
+    good = member(raw)
+    files = {"strict.fq.gz": good, "wrapped.fq.gz": member(b"\n".join(lines)), "multi.fq.gz": member(raw[:9_000_001], 1) + member(raw[9_000_001:], 9),
+             "cut.fq.gz": good[:len(good) * 3 // 5], "crc.fq.gz": good[:-8] + bytes([good[-8] ^ 1]) + good[-7:]}
+    for name, blob in files.items():
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        base = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert base.returncode == 0, base.stderr[-400:]
+        for t, chunk in (("8", "20000"), ("3", "300000"), ("16", "0")):
+            p = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", t, "-v", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               env=dict(os.environ, NTSM_GZ_PARALLEL_MIN="1000", NTSM_GZ_CHUNK=chunk))
+            assert p.returncode == 0, p.stderr[-400:]
+            assert b"parallel gzip:" in p.stderr                        # took the parallel route
+            assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr), (name, t, chunk)
+            if name == "wrapped.fq.gz":
+                assert b"parallel gzip: sequential after" in p.stderr
+
+
 def test_producer_lanes_share_one_context(nt, tmp_path):
     """ntsm_lane_*: four host threads, each with its own lane, feed ONE context concurrently (the reference's
     omp-over-files with a shared m_counts and atomic increments, src/FingerPrint.hpp:47,:94-99).  Counts and totals

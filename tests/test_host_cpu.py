@@ -499,6 +499,136 @@ def test_parallel_gzip_under_tsan_and_asan(nt, tmp_path):
         assert p.returncode == 0, p.stderr.decode()[-3000:]
         out = p.stdout.split()
         assert out[0:2] == [b"%d" % len(data), b"0"] and out[3] == b"0" and out[4:6] == [b"%d" % (2 * len(data) + 5000), b"0"], out[:8]
+        # a reader that walks away in the middle (kseq ends a file at the first malformed record): chunks are being resolved
+        # into pieces at that moment -- nothing may be freed under the workers
+        for stop in (1, 300000, 2000000):
+            p = subprocess.run([exe] + files[:3], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", NTSM_DECODER_THREADS="6", NTSM_PARALLEL_CHUNK="8000", NTSM_STOP_AFTER=str(stop)))
+            assert p.returncode == 0, p.stderr.decode()[-3000:]
+
+
+def _reads_of(bases, ends):
+    bb, out, s = bases.tobytes(), [], 0
+    for x in ends.tolist():
+        out.append(bb[s:x])
+        s = x + 1
+    return out
+
+
+def test_parallel_gzip_ingest_equals_sequential_reader(nt, tmp_path):
+    """Decoder pool + piece-parallel parse (parallel_gz_fastq.hpp) against the sequential reader (itself pinned to kseq) on the
+    same file: the same reads (as a multiset: inside a piece the order may differ, counting does not depend on it), for
+    strict FASTQ, '@' at the start of quality lines, a wrapped record / CRLF / FASTA record in the middle (the sequential
+    reader takes over there), a last record without newline, FASTA, empty and tiny files, several members, BGZF, truncated
+    and CRC-damaged files, chunk sizes from a fraction of a record's worth to bigger than the file, sinks smaller than a
+    piece."""
+    import collections
+    import random
+    from ntsm_amd.capi import flatten_file, flatten_file_parallel_gz, gunzip_parallel_chunk
+    rng = random.Random(3)
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
+    fq = str(tmp_path / "t.fq")
+    s.write_fastq(fq, 0, 30000)
+    raw = open(fq, "rb").read()
+    lines = raw.split(b"\n")
+    cases = {"strict": raw}
+    q = list(lines)
+    for i in range(3, len(q) - 1, 4):                                # quality lines that start with '@' (and some with '+')
+        if rng.random() < 0.3:
+            q[i] = (b"@" if rng.random() < 0.7 else b"+") + q[i][1:]
+    cases["at_qualities"] = b"\n".join(q)
+    w = list(lines)
+    w[60001] = w[60001][:50] + b"\n" + w[60001][50:]                 # one wrapped sequence line in the middle
+    cases["wrapped_mid"] = b"\n".join(w)
+    c = list(lines)
+    c[40000] = c[40000] + b"\r"
+    cases["crlf_mid"] = b"\n".join(c)
+    cases["fasta_mid"] = b"\n".join(lines[:48000]) + b"\n>fa1 x\nACGTACGTACGTACGTACGTAGCTAGCATCGATCGAT\nACGT\n" + b"\n".join(lines[48000:])
+    cases["no_final_newline"] = raw[:-1]
+    cases["fasta"] = b"".join(b">s%d\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(80))) for i in range(20000))
+    cases["junk_first"] = b"junk line\n" + raw
+    cases["empty"] = b""
+    cases["tiny"] = b"@a\nACGT\n+\nFFFF\n"
+    try:
+        for name, data in cases.items():
+            p = str(tmp_path / (name + ".gz"))
+            open(p, "wb").write(_gz_member(data, 6 if name != "strict" else 1))
+            ref_b, ref_e, ref_rc = flatten_file(p)
+            ref = collections.Counter(_reads_of(ref_b, ref_e))
+            for chunk, dec, par, sink in ((3000, 3, 3, 2000), (20000, 4, 5, 1 << 20), (1 << 20, 2, 2, 50000)):
+                gunzip_parallel_chunk(chunk)
+                b, e, info = flatten_file_parallel_gz(p, dec, par, sink)
+                got = collections.Counter(_reads_of(b, e))
+                assert got == ref and len(e) == len(ref_e), (name, chunk, dec, par, sink, len(e), len(ref_e), info)
+                if name in ("strict", "at_qualities"):
+                    assert info["parallel_records"] == len(ref_e)               # nothing left for the sequential reader
+                if name in ("wrapped_mid", "crlf_mid", "fasta_mid"):
+                    assert 0 < info["parallel_records"] < len(ref_e)            # parallel up to the odd record, sequential from there
+                if name in ("fasta", "junk_first"):
+                    assert info["parallel_records"] == 0
+        gunzip_parallel_chunk(20000)
+        # several members (cut anywhere, also inside records), an empty member, trailing garbage
+        p = str(tmp_path / "multi.gz")
+        open(p, "wb").write(_gz_member(raw[:1_000_003], 1) + _gz_member(b"") + _gz_member(raw[1_000_003:4_000_000], 9) + _gz_member(raw[4_000_000:], 6) + b"trailing")
+        ref_b, ref_e, _ = flatten_file(p)
+        b, e, info = flatten_file_parallel_gz(p, 4, 4, 1 << 20)
+        assert collections.Counter(_reads_of(b, e)) == collections.Counter(_reads_of(ref_b, ref_e)) and info["parallel_records"] == len(ref_e) == 30000
+        # BGZF: groups of members inflated in parallel, the same piece-parallel parse behind them
+        p = str(tmp_path / "bgzf.gz")
+        open(p, "wb").write(_bgzf(raw, level=4))
+        b, e, info = flatten_file_parallel_gz(p, 4, 4, 1 << 20)
+        assert collections.Counter(_reads_of(b, e)) == collections.Counter(_reads_of(ref_b, ref_e)) and info["parallel_records"] == 30000 and info["pieces"] >= 2
+        # truncated file: every decodable byte, then a clean end; damaged CRC: every record, status -1
+        good = _gz_member(raw, 6)
+        for cut in (len(good) // 3, len(good) - 5, len(good) - 9):
+            p = str(tmp_path / "cut.gz")
+            open(p, "wb").write(good[:cut])
+            ref_b, ref_e, _ = flatten_file(p)
+            b, e, info = flatten_file_parallel_gz(p, 4, 3, 1 << 20)
+            assert collections.Counter(_reads_of(b, e)) == collections.Counter(_reads_of(ref_b, ref_e)), cut
+        p = str(tmp_path / "crc.gz")
+        open(p, "wb").write(good[:-8] + bytes([good[-8] ^ 1]) + good[-7:])
+        ref_b, ref_e, _ = flatten_file(p)
+        b, e, info = flatten_file_parallel_gz(p, 4, 3, 1 << 20)
+        assert collections.Counter(_reads_of(b, e)) == collections.Counter(_reads_of(ref_b, ref_e)) and info["status"] == -1 and len(e) == 30000
+        bad = bytearray(good)
+        bad[len(good) // 2] ^= 0x40                                    # damage in the middle: same reads as the sequential path up to the error
+        p = str(tmp_path / "bad.gz")
+        open(p, "wb").write(bytes(bad))
+        ref_b, ref_e, _ = flatten_file(p)
+        b, e, info = flatten_file_parallel_gz(p, 4, 3, 1 << 20)
+        assert collections.Counter(_reads_of(b, e)) == collections.Counter(_reads_of(ref_b, ref_e))
+    finally:
+        gunzip_parallel_chunk(0)
+
+
+def test_parallel_gzip_ingest_under_tsan(nt, tmp_path):
+    """Producer, chunk workers and parsing threads of the parallel gzip ingest under ThreadSanitizer: strict file, a file that
+    falls back to the sequential reader in the middle, a truncated one; the same order-free digest whatever the thread counts."""
+    import subprocess
+    exe = str(tmp_path / "parallel_tsan")
+    host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
+    srcs = [os.path.join(ROOT, "tools", "parallel_tsan.cpp")] + [os.path.join(host, f) for f in
+            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "inflate_spec.cpp", "gz_stream.cpp", "gz_parallel.cpp", "crc32_fast.cpp", "pack2.cpp")]
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
+    fq = str(tmp_path / "t.fq")
+    s.write_fastq(fq, 0, 12000)
+    raw = open(fq, "rb").read()
+    lines = raw.split(b"\n")
+    lines[24001] = lines[24001][:50] + b"\n" + lines[24001][50:]
+    good = _gz_member(raw, 6)
+    files = {"strict.gz": good, "wrapped.gz": _gz_member(b"\n".join(lines), 6), "cut.gz": good[:len(good) * 2 // 3]}
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    for name, blob in files.items():
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        outs = set()
+        for dec, par, sink, chunk in ((1, 1, 1 << 20, 20000), (5, 4, 30000, 20000), (3, 6, 1 << 20, 5000), (4, 2, 1 << 20, 1 << 20)):
+            p = subprocess.run([exe, path, str(dec), str(par), str(sink), str(chunk)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert p.returncode == 0, p.stderr.decode()[-3000:]
+            outs.add(p.stdout.split(b" parallel=")[0] + b" " + p.stdout.split(b" ")[-1])
+        assert len(outs) == 1, outs
 
 
 def test_gzip_reader_paths_agree(nt, tmp_path, monkeypatch):

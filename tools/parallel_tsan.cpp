@@ -1,5 +1,7 @@
 /* Driver for running the block-parallel FASTQ ingest under ThreadSanitizer (tests/test_host_cpu.py):
- *   parallel_tsan FILE THREADS BLOCK_BYTES  ->  "reads=N bytes=M parallel=P resume=R" */
+ *   parallel_tsan FILE THREADS BLOCK_BYTES        ->  "reads=N bytes=M parallel=P resume=R fnv=..."
+ *   parallel_tsan FILE.gz DECODERS PARSERS SINK CHUNK  (five arguments: the parallel gzip ingest, parallel_gz_fastq.hpp)
+ *                                                  ->  "reads=N bytes=M parallel=P pieces=Q status=S sum=..." (sum: order-free) */
 #include <cstdio>
 #include <cstdlib>
 
@@ -10,6 +12,26 @@ int main(int argc, char **argv)
 	if (argc < 4) return 2;
 	uint8_t *bases = nullptr;
 	uint64_t *ends = nullptr, nb = 0, nr = 0, nblk = 0, npar = 0, resume = 0;
+	if (argc >= 6) {
+		int st = 0;
+		ntsm_host_gunzip_parallel_chunk(strtoull(argv[5], nullptr, 10));
+		int rc = ntsm_host_flatten_parallel_gz(argv[1], (unsigned) atoi(argv[2]), (unsigned) atoi(argv[3]), strtoull(argv[4], nullptr, 10), &bases, &nb, &ends, &nr,
+				&nblk, &npar, &st);
+		if (rc) { fprintf(stderr, "rc=%d\n", rc); return 1; }
+		/* order-free digest: sum over reads of an FNV hash of the read */
+		uint64_t sum = 0, start = 0;
+		for (uint64_t r = 0; r < nr; ++r) {
+			uint64_t h = 1469598103934665603ull;
+			for (uint64_t i = start; i < ends[r]; ++i) h = (h ^ bases[i]) * 1099511628211ull;
+			sum += h;
+			start = ends[r] + 1;
+		}
+		printf("reads=%llu bytes=%llu parallel=%llu pieces=%llu status=%d sum=%016llx\n", (unsigned long long) nr, (unsigned long long) nb,
+				(unsigned long long) npar, (unsigned long long) nblk, st, (unsigned long long) sum);
+		ntsm_host_free(bases);
+		ntsm_host_free(ends);
+		return 0;
+	}
 	int rc = ntsm_host_flatten_parallel(argv[1], (unsigned) atoi(argv[2]), strtoull(argv[3], nullptr, 10), &bases, &nb, &ends, &nr,
 			&nblk, &npar, &resume);
 	if (rc) { fprintf(stderr, "rc=%d\n", rc); return 1; }
