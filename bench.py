@@ -320,20 +320,71 @@ def config_n10_full(nt, torch, dev, local, args, tmp):
                         SITES_SEED, int(args.n10_full_sites), 13, int(args.n10_full_reads), N10_FULL_TRAFFIC_FILE)
 
 
-def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
-    """File -> counts.txt through the CLI (build/ntsmCount -t N) on a generated plain FASTQ, the whole process timed;
-    its stdout must equal what the resident path prints for the same reads."""
-    n_reads = int(args.e2e_reads)
-    fq = os.path.join(tmp, "e2e.fq")
-    t0 = time.perf_counter()
-    synth.write_fastq(fq, 0, n_reads, threads=max(1, min(32, (os.cpu_count() or 2) - 1)))
-    t_gen = time.perf_counter() - t0
-    size = os.path.getsize(fq)
-    exe = os.path.join(ROOT, "build", "ntsmCount")
+def pigz_like(src, dst, level=6, block=64 << 20, threads=16):
+    """One gzip member holding `src`, written the way pigz does it: blocks of `block` bytes deflated independently by a pool of
+    threads (zlib releases the GIL), every block ended by a sync flush, one final empty block, CRC-32 of the whole (bench tooling:
+    a 12 GB FASTQ through single-threaded gzip -6 would take five minutes)."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    size = os.path.getsize(src)
+
+    def one(off):
+        with open(src, "rb") as f:
+            f.seek(off)
+            data = f.read(block)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return co.compress(data) + co.flush(zlib.Z_SYNC_FLUSH), zlib.crc32(data), len(data)
+    crc = 0
+    with open(dst, "wb") as out, ThreadPoolExecutor(threads) as pool:
+        out.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+        for body, c, n in pool.map(one, range(0, size, block)):
+            out.write(body)
+            crc = _crc32_combine(crc, c, n)
+        out.write(b"\x03\x00")                               # final (empty, fixed-Huffman) block
+        out.write((crc & 0xFFFFFFFF).to_bytes(4, "little") + (size & 0xFFFFFFFF).to_bytes(4, "little"))
+    return os.path.getsize(dst)
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (GF(2) matrix method), which Python's zlib module does not export."""
+    if len2 == 0:
+        return crc1
+
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[n]) for n in range(32)]
+    odd = [0xEDB88320] + [1 << n for n in range(31)]
+    even = square(odd)
+    odd = square(even)
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
+def _run_cli(exe, sites_path, threads, local, path, runs=2):
     best = None
-    for _ in range(2):                                     # second run: file certainly in the page cache
+    for _ in range(runs):                                  # second run: file certainly in the page cache
         t0 = time.perf_counter()
-        p = subprocess.run([exe, "-s", sites_path, "-t", str(args.e2e_threads), "-g", str(local), fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+        p = subprocess.run([exe, "-s", sites_path, "-t", str(threads), "-g", str(local), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            env=dict(os.environ, NTSM_PHASE_TIMES="1"))
         wall = time.perf_counter() - t0
         if p.returncode != 0:
@@ -341,13 +392,26 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
         if best is None or wall < best[0]:
             best = (wall, p)
     wall, p = best
-    os.unlink(fq)
     phases = [l[8:] for l in p.stderr.decode().split("\n") if l.startswith("[phase]")]
     own = [l for l in p.stderr.decode().split("\n") if l.startswith("Time: ")]          # the CLI's own clock, main() to the last print
-    cli_s = float(own[-1].split()[1]) if own else None
+    return wall, p, phases, (float(own[-1].split()[1]) if own else None)
+
+
+def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
+    """File -> counts.txt through the CLI (build/ntsmCount -t N) on a generated plain FASTQ, the whole process timed;
+    its stdout must equal what the resident path prints for the same reads.  Then the same reads as ONE ordinary gzip member
+    (`e2e_cli_gz`: decoder pool + piece-parallel parse, gz_stream.hpp / parallel_gz_fastq.hpp): identical counts.txt."""
+    n_reads = int(args.e2e_reads)
+    fq = os.path.join(tmp, "e2e.fq")
+    t0 = time.perf_counter()
+    synth.write_fastq(fq, 0, n_reads, threads=max(1, min(32, (os.cpu_count() or 2) - 1)))
+    t_gen = time.perf_counter() - t0
+    size = os.path.getsize(fq)
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    wall, p, phases, cli_s = _run_cli(exe, sites_path, args.e2e_threads, local, fq)
     parse_s = None
     for l in phases:
-        if "parse+count" in l:
+        if "parse+count" in l and "inflate" not in l:
             try:
                 parse_s = float(l.split("parse+count")[1].split("s")[0])
             except ValueError:
@@ -367,11 +431,42 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
     sha_cli, sha_res = hashlib.sha256(p.stdout).hexdigest(), hashlib.sha256(text).hexdigest()
     assert rc == 0 and sha_cli == sha_res, "CLI counts.txt differs from the resident path's"
     bases = n_reads * READ_LEN
-    return {"workload": "build/ntsmCount -t %d on one plain FASTQ of %.3g reads (%.1f GB, page cache), hs_n10_like sites" % (args.e2e_threads, n_reads, size / 1e9),
-            "reads": n_reads, "file_bytes": size, "wall_s": wall, "gbases_per_s": bases / wall / 1e9,
-            "cli_reported_s": cli_s,       # inside the process; wall_s also holds its spawn from this (large) parent and its exit
-            "parse_and_count_s": parse_s, "gbases_per_s_parse_and_count": bases / parse_s / 1e9 if parse_s else None,
-            "phases": phases, "fastq_gen_s": t_gen, "counts_sha256": sha_cli, "check": {"counts_txt_equals_resident_path": True}}
+    out = {"workload": "build/ntsmCount -t %d on one plain FASTQ of %.3g reads (%.1f GB, page cache), hs_n10_like sites" % (args.e2e_threads, n_reads, size / 1e9),
+           "reads": n_reads, "file_bytes": size, "wall_s": wall, "gbases_per_s": bases / wall / 1e9,
+           "cli_reported_s": cli_s,       # inside the process; wall_s also holds its spawn from this (large) parent and its exit
+           "parse_and_count_s": parse_s, "gbases_per_s_parse_and_count": bases / parse_s / 1e9 if parse_s else None,
+           "phases": phases, "fastq_gen_s": t_gen, "counts_sha256": sha_cli, "check": {"counts_txt_equals_resident_path": True}}
+    gz_out = None
+    try:
+        gz = os.path.join(tmp, "e2e.fq.gz")
+        t0 = time.perf_counter()
+        gz_size = pigz_like(fq, gz, threads=max(1, min(48, (os.cpu_count() or 2) - 1)))
+        t_gz = time.perf_counter() - t0
+        os.unlink(fq)
+        wall, pz, phases, cli_s = _run_cli(exe, sites_path, args.e2e_threads, local, gz)
+        os.unlink(gz)
+        assert hashlib.sha256(pz.stdout).hexdigest() == sha_cli, "counts.txt of the .gz run differs from the plain FASTQ's"
+        infl = None
+        for l in phases:
+            if "inflate+parse+count" in l:
+                try:
+                    infl = float(l.split("inflate+parse+count")[1].split("s")[0])
+                except ValueError:
+                    pass
+        gz_out = {"workload": "build/ntsmCount -t %d on the same reads as ONE gzip member (%.2f GB; level 6, written pigz-style in 64 MiB blocks)" % (args.e2e_threads, gz_size / 1e9),
+                  "reads": n_reads, "file_bytes": gz_size, "text_bytes": size, "wall_s": wall, "gbases_per_s": bases / wall / 1e9, "cli_reported_s": cli_s,
+                  "inflate_parse_count_s": infl, "gbases_per_s_inflate_parse_count": bases / infl / 1e9 if infl else None,
+                  "text_GB_per_s_inflate_parse_count": size / infl / 1e9 if infl else None, "phases": phases, "gzip_s": t_gz,
+                  "check": {"counts_txt_equals_plain_fastq_run": True}}
+    except AssertionError:
+        raise
+    except Exception as e:
+        gz_out = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    finally:
+        for f in (fq, os.path.join(tmp, "e2e.fq.gz")):
+            if os.path.exists(f):
+                os.unlink(f)
+    return out, gz_out
 
 
 def run_rank(args):
@@ -619,7 +714,7 @@ def run_rank(args):
                     elif name == "n10_full":
                         other["n10_full"] = config_n10_full(ntsm_amd, torch, dev, local, args, tmp)
                     elif name == "e2e":
-                        other["e2e_cli"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp)
+                        other["e2e_cli"], other["e2e_cli_gz"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp)
                     else:
                         continue
                 except AssertionError:

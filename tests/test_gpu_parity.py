@@ -1292,7 +1292,8 @@ def test_bench_contract_line(nt):
     assert d["check"]["equals_generic_kernel_sum_of_pieces_below_2GiB"] is True
     # the secondary configurations ride on the same line, each with its own check (configs[2], configs[4], CLI)
     o = d["other_configs"]
-    assert set(o) == {"long", "stress", "n10_full", "e2e_cli"} and not any("error" in v for v in o.values()), o
+    assert set(o) == {"long", "stress", "n10_full", "e2e_cli", "e2e_cli_gz"} and not any("error" in v for v in o.values()), o
+    assert o["e2e_cli_gz"]["check"]["counts_txt_equals_plain_fastq_run"] and o["e2e_cli_gz"]["wall_s"] > 0
     assert o["n10_full"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["n10_full"]["site_kmers"] == 2 * 13 * 20000
     assert o["long"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["long"]["gbases_per_s"] > 0 and 0 < o["long"]["roofline_frac"] < 1
     assert o["long"]["m10"]["early_stop"] in (True, False) and o["long"]["m10"]["stop_read"] <= o["long"]["reads"]
