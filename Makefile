@@ -21,12 +21,12 @@ HOSTHDR  := $(wildcard $(HOST)/*.hpp) include/ntsm_host.h include/ntsm_hip.h
 all: oracle_all build/ntsm_synth build/gather_bench ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount ntsm_amd/libntsm_eval_hip.so build/ntsmEval
 
 # host-only pieces (reader, site loader, report formatting): no HIP dependency
-ntsm_amd/libntsm_host.so: $(HOSTSRC) $(HOST)/host_capi.cpp $(HOSTHDR)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC) $(HOST)/host_capi.cpp -lz -pthread
+ntsm_amd/libntsm_host.so: $(HOSTSRC) $(HOST)/early_ingest.cpp $(HOST)/host_capi.cpp $(HOSTHDR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC) $(HOST)/early_ingest.cpp $(HOST)/host_capi.cpp -lz -pthread
 
-build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp $(HOSTHDR) ntsm_amd/libntsm_hip.so
+build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/early_ingest.cpp $(HOST)/ntsm_count_main.cpp $(HOSTHDR) ntsm_amd/libntsm_hip.so
 	@mkdir -p build
-	$(CXX) $(CXXFLAGS) -o $@ $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/ntsm_count_main.cpp \
+	$(CXX) $(CXXFLAGS) -o $@ $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/early_ingest.cpp $(HOST)/ntsm_count_main.cpp \
 	    -Lntsm_amd -lntsm_hip -lz -pthread -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
 ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_device.h include/ntsm_hip.h

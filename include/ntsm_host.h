@@ -48,7 +48,7 @@ const char *ntsm_host_pack2_impl(void);
  * (free with ntsm_host_free); returns the last read's result: 0 = clean end, -1 = error, -2 = cannot open. */
 int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out, uint64_t *len);
 /* Test hook: compressed bytes per chunk of the parallel decoder for plain (non-BGZF) gzip input that engine n >= 2 uses
- * (0 = the default 2 MiB; files shorter than two chunks are decoded in order).  stats, if not NULL, receives what the last
+ * (0 = the default 1 MiB; files shorter than two chunks are decoded in order).  stats, if not NULL, receives what the last
  * ntsm_host_gunzip call with engine >= 2 did: [0] chunks spliced in, [1] chunks dropped (no block start found in their
  * range, start not confirmed by the in-order decoder, or decoding failed). */
 /* Test hook for the parallel gzip ingest (parallel_gz_fastq.hpp over gz_stream.hpp): n_decoders decoder threads inflate
@@ -58,6 +58,12 @@ int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out
  * gzip, -1 if it cannot be opened.  *n_parallel = records committed by the parallel phase. */
 int ntsm_host_flatten_parallel_gz(const char *path, unsigned n_decoders, unsigned n_parsers, uint64_t sink_bytes, uint8_t **bases,
 		uint64_t *n_bytes, uint64_t **read_end, uint64_t *n_reads, uint64_t *n_pieces, uint64_t *n_parallel, int *final_status);
+/* Test hook for the early ingest (ntsm_amd/csrc/host/early_ingest.hpp): parse `path` (plain FASTQ or gzip) into packed chunks
+ * of chunk_positions positions, at most max_chunks at once, drained by n_consumers threads.  *text receives every position of
+ * every chunk as 'A' 'C' 'G' 'T' (valid) or 'N' (invalid / terminator), chunks separated by 'N' -- so the maximal runs of
+ * letters are the maximal runs of valid bases of the reads.  Returns 0, 1 if the file is not taken by this path. */
+int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions, uint64_t max_chunks,
+		unsigned n_consumers, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases, uint64_t *n_parallel);
 void ntsm_host_gunzip_parallel_chunk(uint64_t bytes);
 void ntsm_host_gunzip_parallel_stats(uint64_t stats[2]);
 /* Block-parallel variant for plain 4-line FASTQ (ntsm_amd/csrc/host/parallel_fastq.hpp), for tests: the records

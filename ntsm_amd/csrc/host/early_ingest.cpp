@@ -1,0 +1,177 @@
+#include "early_ingest.hpp"
+
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+#include "gz_stream.hpp"
+#include "pack2.hpp"
+#include "parallel_fastq.hpp"
+#include "parallel_gz_fastq.hpp"
+#include "seq_reader.hpp"
+
+namespace ntsm {
+
+bool EarlyIngest::Sink::has_room(uint64_t len) const
+{
+	return !m_cur || pack2_extent(m_cur->pos, len) <= m_cur->cap;
+}
+
+void EarlyIngest::Sink::feed(const char *seq, uint64_t len)
+{
+	if (!m_cur) {
+		m_cur = m_owner->blank(pack2_extent(0, len));
+		if (!m_cur) return;                                    /* the run is being abandoned */
+	}
+	m_cur->pos = pack2_append(m_cur->codes.get(), m_cur->valid.get(), m_cur->pos, seq, len);
+	m_cur->n_bases += len;
+	++m_cur->n_reads;
+	++fed;
+}
+
+void EarlyIngest::Sink::flush()
+{
+	if (m_cur && m_cur->n_reads) m_owner->publish(std::move(m_cur));
+}
+
+void EarlyIngest::Sink::discard()
+{
+	if (m_cur) {
+		fed -= m_cur->n_reads;
+		m_cur->pos = m_cur->n_bases = 0;
+		m_cur->n_reads = 0;
+	}
+}
+
+std::unique_ptr<PackedChunk> EarlyIngest::blank(uint64_t min_positions)
+{
+	std::unique_ptr<PackedChunk> c;
+	{
+		std::unique_lock<std::mutex> lk(m_mu);
+		m_cv.wait(lk, [&]() { return m_abandon || m_out < m_maxChunks; });
+		if (m_abandon) return nullptr;
+		++m_out;
+		if (!m_free.empty()) { c = std::move(m_free.front()); m_free.pop_front(); }
+	}
+	const uint64_t want = std::max<uint64_t>(m_chunkPositions, (min_positions + 31) & ~31ull);
+	if (!c) c.reset(new PackedChunk());
+	if (c->cap < want) {
+		c->codes.reset(new uint8_t[want / 4]);
+		c->valid.reset(new uint8_t[want / 8]);
+		c->cap = want;
+	}
+	c->pos = c->n_bases = 0;
+	c->n_reads = 0;
+	return c;
+}
+
+void EarlyIngest::publish(std::unique_ptr<PackedChunk> c)
+{
+	{
+		std::lock_guard<std::mutex> lk(m_mu);
+		m_ready.push_back(std::move(c));
+	}
+	m_cv.notify_all();
+}
+
+void EarlyIngest::recycle(std::unique_ptr<PackedChunk> c)
+{
+	{
+		std::lock_guard<std::mutex> lk(m_mu);
+		if (m_free.size() < 64) m_free.push_back(std::move(c));
+		--m_out;
+	}
+	m_cv.notify_all();
+}
+
+bool EarlyIngest::next(std::unique_ptr<PackedChunk> *out)
+{
+	std::unique_lock<std::mutex> lk(m_mu);
+	m_cv.wait(lk, [&]() { return m_done || !m_ready.empty(); });
+	if (m_ready.empty()) return false;
+	*out = std::move(m_ready.front());
+	m_ready.pop_front();
+	return true;
+}
+
+EarlyIngest::EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t gz_min_bytes, uint64_t chunk_positions, size_t max_chunks)
+	: m_path(std::move(path)), m_nParsers(n_parsers ? n_parsers : 1), m_nDecoders(n_decoders ? n_decoders : 1), m_blockBytes(block_bytes),
+	  m_chunkPositions(chunk_positions & ~31ull), m_maxChunks(max_chunks < 2 * (size_t) (n_parsers ? n_parsers : 1) ? 2 * (size_t) (n_parsers ? n_parsers : 1) : max_chunks)
+{
+	struct stat st;
+	if (stat(m_path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return;
+	m_plain.reset(new ParallelFastq());
+	if (m_plain->open(m_path, m_blockBytes)) {
+		m_how = "plain FASTQ, block-parallel";
+	} else {
+		m_plain.reset();
+		if (getenv("NTSM_ZLIB_ONLY") || (uint64_t) st.st_size < gz_min_bytes || !GzStream::is_gzip(m_path)) return;
+		GzStream::set_decoder_threads(m_nDecoders);
+		m_gz.reset(new GzStream());
+		const bool ok = m_gz->open(m_path);
+		GzStream::set_decoder_threads(1);
+		if (!ok) { m_gz.reset(); return; }
+		m_how = "gzip, decoder pool + piece-parallel";
+	}
+	m_taken = true;
+	m_thread = std::thread([this]() { run(); });
+}
+
+EarlyIngest::~EarlyIngest()
+{
+	{
+		std::lock_guard<std::mutex> lk(m_mu);
+		m_abandon = true;
+	}
+	m_cv.notify_all();
+	if (m_thread.joinable()) m_thread.join();
+}
+
+void EarlyIngest::run()
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	std::vector<Sink> sinks;
+	sinks.reserve(m_nParsers);
+	for (unsigned i = 0; i < m_nParsers; ++i) sinks.emplace_back(this);
+	std::vector<Sink *> ptrs;
+	for (auto &s : sinks) ptrs.push_back(&s);
+	auto sequential = [&](SeqReader &rd) {                     /* what the parallel phase left: kseq-exact, into the first sink */
+		Sink &s = sinks[0];
+		for (int64_t l = rd.next(); l >= 0; l = rd.next()) {
+			if (!s.has_room((uint64_t) l)) s.flush();
+			s.feed(rd.seq_data(), (uint64_t) l);
+		}
+		s.flush();
+	};
+	if (m_plain) {
+		const ParallelFastq::Result r = m_plain->run(ptrs);
+		m_parallelRecords = r.records;
+		if (!r.complete) {
+			SeqReader rd;
+			if (rd.open(m_path, r.resume)) sequential(rd);
+		}
+		m_plain.reset();
+	} else {
+		ParallelGzFastq pg(m_gz.get());
+		const ParallelGzFastq::Result r = pg.run(ptrs);
+		m_parallelRecords = r.records;
+		if (!r.complete) {
+			SeqReader rd;
+			if (rd.open_stream(std::move(m_gz))) sequential(rd);
+		}
+		m_gz.reset();
+	}
+	uint64_t n = 0;
+	for (auto &s : sinks) { s.flush(); n += s.fed; }
+	m_records = n;
+	m_parseSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	{
+		std::lock_guard<std::mutex> lk(m_mu);
+		m_done = true;
+	}
+	m_cv.notify_all();
+}
+
+} // namespace ntsm

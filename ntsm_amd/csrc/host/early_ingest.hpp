@@ -1,0 +1,96 @@
+/*
+ * early_ingest.hpp -- parsing that starts before the GPU context exists (the reference's clock,
+ * src/ntSeqMatchCount.cpp:175-182, covers the table build and the scan one after the other).
+ *
+ * A run spends its first 0.25-0.3 s loading the sites file and building / uploading the tables; nothing of that depends on
+ * the reads.  With -t N (and no -m: the result then does not depend on the order of the reads) the first input file is
+ * therefore opened at once and parsed by the same block-parallel machinery as later (parallel_fastq.hpp for a plain FASTQ,
+ * parallel_gz_fastq.hpp over the decoder pool for gzip), only into ordinary memory instead of pinned lane slots: every
+ * parsing thread packs its reads (pack2.hpp: 2-bit codes + validity bits, 3/8 byte per position) into chunks laid out
+ * exactly like a packed lane slot.  Once the context is there, the feeders copy the finished chunks into their lanes and
+ * submit them (Feeder::submitChunk) while the rest of the file is still being parsed.  What the parallel phase cannot take
+ * (records that are not plain 4-line FASTQ) goes through the sequential reader into the same chunks, so the whole file is
+ * covered either way; a file that cannot be opened is left to the ordinary path, which reports it like the reference.
+ * The chunks in flight are bounded (a feeder that is not there yet makes the parsers wait).
+ */
+#ifndef NTSM_EARLY_INGEST_HPP
+#define NTSM_EARLY_INGEST_HPP
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace ntsm {
+
+class ParallelFastq;
+class GzStream;
+
+struct PackedChunk {                                   /* one packed batch in ordinary memory, laid out like a packed lane slot */
+	std::unique_ptr<uint8_t[]> codes, valid;           /* cap / 4 and cap / 8 bytes */
+	uint64_t cap = 0, pos = 0, n_bases = 0;            /* positions: capacity, used; sum of the read lengths */
+	uint32_t n_reads = 0;
+};
+
+class EarlyIngest {
+public:
+	/* chunk_positions: capacity of a chunk (= of a feeder's packed lane slot); max_chunks: chunks that may exist at once */
+	EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t gz_min_bytes, uint64_t chunk_positions, size_t max_chunks);
+	~EarlyIngest();
+	EarlyIngest(const EarlyIngest &) = delete;
+	EarlyIngest &operator=(const EarlyIngest &) = delete;
+
+	bool taken() const { return m_taken; }             /* false: the file is not for this path (not there, tiny, FIFO ...): use the ordinary one */
+	/* next finished chunk; false once the file has been consumed entirely and every chunk has been handed out */
+	bool next(std::unique_ptr<PackedChunk> *out);
+	void recycle(std::unique_ptr<PackedChunk> c);      /* hand a drained chunk back (its memory is reused) */
+	/* statistics for the phase line, valid after next() returned false */
+	uint64_t records() const { return m_records; }
+	uint64_t parallel_records() const { return m_parallelRecords; }
+	const std::string &how() const { return m_how; }
+	double parse_seconds() const { return m_parseSeconds; }
+
+	/* Sink of the parallel parsers (parallel_fastq.hpp): one per parsing thread */
+	class Sink {
+	public:
+		explicit Sink(EarlyIngest *owner) : m_owner(owner) {}
+		bool has_room(uint64_t len) const;
+		void feed(const char *seq, uint64_t len);
+		void flush();
+		void discard();
+		void begin_block(size_t) {}
+		uint64_t fed = 0;
+	private:
+		EarlyIngest *m_owner;
+		std::unique_ptr<PackedChunk> m_cur;
+	};
+
+private:
+	friend class Sink;
+	void run();
+	std::unique_ptr<PackedChunk> blank(uint64_t min_positions);   /* waits while max_chunks are out */
+	void publish(std::unique_ptr<PackedChunk> c);
+
+	const std::string m_path;
+	const unsigned m_nParsers, m_nDecoders;
+	const uint64_t m_blockBytes, m_chunkPositions;
+	const size_t m_maxChunks;
+	bool m_taken = false;
+	std::unique_ptr<ParallelFastq> m_plain;            /* exactly one of the two when taken */
+	std::unique_ptr<GzStream> m_gz;
+	std::thread m_thread;
+	std::mutex m_mu;
+	std::condition_variable m_cv;
+	std::deque<std::unique_ptr<PackedChunk>> m_ready, m_free;
+	size_t m_out = 0;                                  /* chunks that exist outside m_free */
+	bool m_done = false, m_abandon = false;
+	uint64_t m_records = 0, m_parallelRecords = 0;
+	std::string m_how;
+	double m_parseSeconds = 0;
+};
+
+} // namespace ntsm
+#endif

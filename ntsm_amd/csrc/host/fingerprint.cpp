@@ -11,6 +11,7 @@
 #include <thread>
 #include <sys/stat.h>
 
+#include "early_ingest.hpp"
 #include "gz_stream.hpp"
 #include "pack2.hpp"
 #include "parallel_fastq.hpp"
@@ -149,6 +150,35 @@ void Feeder::feedStream(std::unique_ptr<GzStream> gz)
 	}
 }
 
+void Feeder::submitChunk(const PackedChunk &c)
+{
+	if (!m_packed || c.n_reads == 0) return;
+	flush();                                                   /* own staging first: the slot must be free */
+	if (m_codes) {                                             /* held but empty (after discard()): hand it back */
+		int rc = ntsm_lane_submit_packed(m_lane, 0, 0, 0);
+		if (rc) die(rc, "cannot return an empty staging slot");
+		m_codes = m_valid = nullptr;
+	}
+	const uint64_t need = (c.pos + 31) & ~31ull;               /* pack2 writes whole groups of 32 positions */
+	if (need > (m_cfgBytes & ~31ull)) {                        /* a chunk grown for a very long read: grow both slots */
+		m_cfgBytes = need + need / 2;
+		int rc = ntsm_lane_close(m_lane);
+		m_lane = nullptr;
+		if (rc) die(rc, "cannot grow staging buffers");
+		openLane();
+	}
+	int rc = ntsm_lane_acquire_packed(m_lane, &m_codes, &m_valid, &m_capPos);
+	if (rc) die(rc, "cannot acquire staging");
+	if (m_capPos < need) die(NTSM_ERR_ARG, "staging slot smaller than an early chunk");
+	memcpy(m_codes, c.codes.get(), need / 4);
+	memcpy(m_valid, c.valid.get(), need / 8);
+	rc = ntsm_lane_submit_packed(m_lane, c.pos, c.n_reads, c.n_bases);
+	if (rc) die(rc, "submit failed");
+	m_codes = m_valid = nullptr;
+	m_pos = m_nBases = 0;
+	m_nReads = 0;
+}
+
 void Feeder::progressLine()
 {
 	flush();                                               /* may trip the -m threshold: the line is printed all the same, like the reference's */
@@ -246,6 +276,20 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 				if (ntsm_warmup(d, lanes_per_dev ? 5 : 3) != NTSM_OK) return;   /* a context's 3 streams + its 2 lane streams; ntsm_create reports failures */
 				if (first) (void) ntsm_staging_pool(pool_bytes);
 			});
+		}
+	}
+	/* the first input file starts being parsed now, into ordinary memory (early_ingest.hpp): -t N, no -m, no -vvv */
+	{
+		const bool maybe_armed = m_opt.covThresh != 0 && m_opt.covThresh < 1e300;
+		if (m_opt.early && m_opt.pack && m_opt.threads > 1 && !maybe_armed && m_opt.verbose <= 2 && !m_opt.inputs.empty()) {
+			const unsigned n_par = std::min(m_opt.threads, 16u);
+			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+			const unsigned n_dec = m_opt.gz_decoders ? m_opt.gz_decoders : std::min(std::min(20u, hw), 2 * m_opt.threads);
+			const uint64_t chunk_pos = std::max<uint64_t>(4096, std::min<uint64_t>(std::max<uint64_t>(4096, m_opt.batch_bytes), lane_bytes(m_opt.threads))) & ~31ull;
+			const size_t max_chunks = (size_t) std::max<uint64_t>(4 * n_par, (4ull << 30) / (chunk_pos * 3 / 8 + 1));   /* 4 GiB of packed reads at most */
+			m_early.reset(new EarlyIngest(m_opt.inputs[0], n_par, n_dec, std::min<uint64_t>(m_opt.block_bytes, 2 * lane_bytes(m_opt.threads)),
+			                              m_opt.gz_parallel_min_bytes, chunk_pos, max_chunks));
+			if (!m_early->taken()) m_early.reset();
 		}
 	}
 	const bool loaded = m_sites.load(m_opt.snp, m_opt.k, m_opt.dupes, std::cerr);
@@ -346,10 +390,17 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 		return;
 	}
 	m_lanes.resize(want);
+	std::vector<std::string> todo(filenames);
+	if (m_early && !todo.empty() && todo[0] == m_opt.inputs[0]) {
+		drainEarly();                                            /* the first file has been in the works since the process started */
+		todo.erase(todo.begin());
+	}
+	m_early.reset();
+	const std::vector<std::string> &files_left = todo;
 	/* Big plain FASTQ files are cut into blocks and parsed by all threads (parallel_fastq.hpp); files that are not
 	 * eligible (gzip, FASTA, wrapped or CR lines, small) are taken whole, one thread per file. */
 	std::vector<std::string> rest;
-	for (const std::string &fn : filenames) {
+	for (const std::string &fn : files_left) {
 		ParallelFastq pf;
 		/* a block's sequences + terminators (at most half its bytes: a record is header + SEQ + '+' line + QUAL) must
 		 * fit one lane slot, so that no thread waits for its predecessor in the middle of a block */
@@ -389,7 +440,10 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 			const auto tp0 = std::chrono::steady_clock::now();
 			const size_t n_par = std::min<size_t>(want, 16);
 			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-			const unsigned n_dec = (unsigned) std::min<size_t>(std::min<size_t>(64, hw), 2 * want);
+			/* decoder threads: twice the feeders, at most 20 -- measured on a 2 x 64-core host (6.3 GB of text, 1 MiB chunks): 16
+			 * decoders deliver 12-13 GB/s, 32 no more than that, 64 less (they fall over each other in the memory system) */
+			unsigned n_dec = (unsigned) std::min<size_t>(std::min<size_t>(20, hw), 2 * want);
+			if (m_opt.gz_decoders) n_dec = m_opt.gz_decoders;
 			GzStream::set_decoder_threads(n_dec);
 			std::unique_ptr<GzStream> gz(new GzStream());
 			if (!gz->open(fn)) { small.push_back(fn); continue; }
@@ -437,6 +491,37 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 	const auto tc0 = std::chrono::steady_clock::now();
 	closeLanes();
 	if (m_opt.phase_times) std::cerr << "[phase] lanes closed in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count() << " s" << std::endl;
+}
+
+void FingerPrint::drainEarly()
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	const size_t n_par = std::min<size_t>(m_lanes.size(), 16);
+	if (m_opt.verbose) std::cerr << "Opening " << m_opt.inputs[0] << "\n" << "early ingest (" << m_early->how() << "): parsed while the sites were loading" << std::endl;
+	{
+		std::vector<std::thread> mk;                         /* lanes (pinned staging) are allocated in parallel */
+		for (size_t t = 0; t < n_par; ++t) mk.emplace_back([this, t]() { (void) feederFor(t); });
+		for (auto &th : mk) th.join();
+	}
+	const auto t1 = std::chrono::steady_clock::now();
+	std::atomic<uint64_t> chunks(0);
+	std::vector<std::thread> pool;
+	for (size_t t = 0; t < n_par; ++t)
+		pool.emplace_back([this, t, &chunks]() {
+			Feeder &f = feederFor(t);
+			std::unique_ptr<PackedChunk> c;
+			while (m_early->next(&c)) {
+				f.submitChunk(*c);
+				m_early->recycle(std::move(c));
+				++chunks;
+			}
+		});
+	for (auto &th : pool) th.join();
+	if (m_opt.phase_times)
+		std::cerr << "[phase] " << m_opt.inputs[0] << ": early ingest (" << m_early->how() << ") parsed " << m_early->records() << " records ("
+		          << m_early->parallel_records() << " in parallel) in " << m_early->parse_seconds() << " s beside the start-up; lanes "
+		          << std::chrono::duration<double>(t1 - t0).count() << " s, " << chunks.load() << " chunks submitted in "
+		          << std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() << " s after the context was ready" << std::endl;
 }
 
 void FingerPrint::fetchResults()

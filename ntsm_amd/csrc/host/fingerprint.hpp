@@ -39,6 +39,11 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	/* gzip inputs of at least this many (compressed) bytes take the parallel route with -t N: decoder pool + piece-parallel
 	 * parsing (gz_stream.hpp, parallel_gz_fastq.hpp); smaller ones are read one thread per file */
 	uint64_t gz_parallel_min_bytes = 8ull << 20;
+	unsigned gz_decoders = 0;              /* NTSM_GZ_DECODERS: decoder threads of that route (0 = automatic) */
+	/* The input files, known before the sites are loaded: with -t N and no -m the first one is parsed into ordinary memory
+	 * while the sites load and the tables build (early_ingest.hpp; NTSM_NO_EARLY=1 switches that off) */
+	std::vector<std::string> inputs;
+	bool early = true;
 };
 
 /* The staging batch one host thread is filling for a GPU context: the context's own slots (single-threaded and
@@ -53,6 +58,8 @@ public:
 	void feedFile(const std::string &path, uint64_t offset = 0);
 	/* the same on an open gzip stream positioned at a record boundary (what a parallel phase left, parallel_gz_fastq.hpp) */
 	void feedStream(std::unique_ptr<class GzStream> gz);
+	/* a batch that was packed in ordinary memory before this lane existed (early_ingest.hpp): copied into a slot and submitted */
+	void submitChunk(const struct PackedChunk &c);
 	/* One read (insertCount(seq.s, seq.l), src/FingerPrint.hpp:89-103): append to the staging batch. */
 	void feedRead(const char *seq, uint64_t len);
 	void flush();
@@ -119,6 +126,8 @@ private:
 	std::vector<int> m_ctxDevice;
 	std::unique_ptr<Feeder> m_main;                      /* context [0]'s own staging: single-threaded and -m runs */
 	std::vector<std::unique_ptr<Feeder>> m_lanes;        /* -t N: one producer lane per host thread */
+	std::unique_ptr<class EarlyIngest> m_early;          /* the first input file, parsed while the sites load (early_ingest.hpp) */
+	void drainEarly();                                   /* its chunks -> the lanes */
 	/* results */
 	bool m_fetched = false;
 	ntsm_totals m_totals {};

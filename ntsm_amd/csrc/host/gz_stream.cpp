@@ -72,14 +72,14 @@ size_t bgzf_member_size(const uint8_t *p, size_t n)
 }
 
 std::atomic<unsigned> g_decoder_threads { 1 };
-std::atomic<size_t> g_parallel_chunk { 2u << 20 };
+std::atomic<size_t> g_parallel_chunk { 1u << 20 };   /* measured: 0.5 / 1 / 2 / 4 MiB -> 0.71 / 0.51 / 0.57 / 0.89 s for a 1.05 GB .gz with 16 + 32 threads */
 std::atomic<uint64_t> g_par_spliced { 0 }, g_par_dropped { 0 };
 } // namespace
 
 void GzStream::last_parallel_stats(uint64_t out[2]) { out[0] = g_par_spliced; out[1] = g_par_dropped; }
 
 void GzStream::set_decoder_threads(unsigned n) { g_decoder_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
-void GzStream::set_parallel_chunk(size_t bytes) { g_parallel_chunk = bytes ? std::max<size_t>(bytes, 1024) : (2u << 20); }
+void GzStream::set_parallel_chunk(size_t bytes) { g_parallel_chunk = bytes ? std::max<size_t>(bytes, 1024) : (1u << 20); }
 
 bool GzStream::is_gzip(const std::string &path)
 {

@@ -48,7 +48,7 @@ public:
 	static bool is_gzip(const std::string &path);      /* regular file that starts with 1f 8b */
 	/* decoder threads used for BGZF input by streams opened from now on (process-wide; default 1 = sequential) */
 	static void set_decoder_threads(unsigned n);
-	/* compressed bytes per chunk of the parallel decoder for plain gzip (process-wide; default 2 MiB; 0 = default) */
+	/* compressed bytes per chunk of the parallel decoder for plain gzip (process-wide; default 1 MiB; 0 = default) */
 	static void set_parallel_chunk(size_t bytes);
 	/* what the most recently finished parallel decode did (process-wide, for tests and -v): chunks spliced / dropped */
 	static void last_parallel_stats(uint64_t out[2]);

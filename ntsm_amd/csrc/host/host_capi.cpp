@@ -10,6 +10,7 @@
 
 #include "gz_stream.hpp"
 #include "pack2.hpp"
+#include "early_ingest.hpp"
 #include "parallel_fastq.hpp"
 #include "parallel_gz_fastq.hpp"
 #include "report.hpp"
@@ -237,6 +238,45 @@ int ntsm_host_flatten_parallel_gz(const char *path, unsigned n_decoders, unsigne
 	if (n_pieces) *n_pieces = r.pieces;
 	if (final_status) *final_status = r.status;
 	return 0;
+}
+
+int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions, uint64_t max_chunks,
+		unsigned n_consumers, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases, uint64_t *n_parallel)
+{
+	ntsm::EarlyIngest ei(path, n_parsers, n_decoders, block_bytes, 1000, chunk_positions, (size_t) max_chunks);
+	if (!ei.taken()) return 1;
+	std::mutex mu;
+	std::vector<uint8_t> all;
+	uint64_t reads = 0, bases = 0;
+	std::vector<std::thread> pool;
+	for (unsigned t = 0; t < (n_consumers ? n_consumers : 1); ++t)
+		pool.emplace_back([&]() {
+			std::unique_ptr<ntsm::PackedChunk> c;
+			std::vector<uint8_t> mine;
+			uint64_t r = 0, b = 0;
+			while (ei.next(&c)) {
+				for (uint64_t p = 0; p < c->pos; ++p) {
+					const bool v = (c->valid[p >> 3] >> (p & 7)) & 1;
+					mine.push_back(v ? (uint8_t) "ACGT"[(c->codes[p >> 2] >> (2 * (p & 3))) & 3] : (uint8_t) 'N');
+				}
+				mine.push_back('N');
+				r += c->n_reads;
+				b += c->n_bases;
+				ei.recycle(std::move(c));
+			}
+			std::lock_guard<std::mutex> lk(mu);
+			all.insert(all.end(), mine.begin(), mine.end());
+			reads += r;
+			bases += b;
+		});
+	for (auto &th : pool) th.join();
+	*text = (uint8_t *) malloc(all.size() + 1);
+	memcpy(*text, all.data(), all.size());
+	*n_text = all.size();
+	*n_reads = reads;
+	*n_bases = bases;
+	if (n_parallel) *n_parallel = ei.parallel_records();
+	return reads == ei.records() ? 0 : -2;
 }
 
 int ntsm_host_format_counts(const ntsm_sites *s, const uint64_t *counts, uint64_t total_kmers, char **out, size_t *len)

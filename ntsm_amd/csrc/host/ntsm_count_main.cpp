@@ -147,6 +147,7 @@ int main(int argc, char *argv[])
 	if (getenv("NTSM_NO_PACK")) opt.pack = false;                                                  /* lanes send raw bytes instead of 2-bit codes + validity */
 	if (const char *pb = getenv("NTSM_BLOCK_BYTES")) opt.block_bytes = strtoull(pb, nullptr, 10);   /* block-parallel ingest block size */
 	if (const char *gm = getenv("NTSM_GZ_PARALLEL_MIN")) opt.gz_parallel_min_bytes = strtoull(gm, nullptr, 10);   /* smallest gzip file that takes the decoder pool + piece-parallel parse (-t N) */
+	if (const char *gd = getenv("NTSM_GZ_DECODERS")) opt.gz_decoders = (unsigned) strtoul(gd, nullptr, 10);     /* decoder threads of that route */
 	if (const char *gc = getenv("NTSM_GZ_CHUNK")) ntsm::GzStream::set_parallel_chunk(strtoull(gc, nullptr, 10));  /* compressed bytes per chunk of the parallel gzip decoder */
 	const auto t0 = std::chrono::steady_clock::now();
 	const bool phases = opt.phase_times = getenv("NTSM_PHASE_TIMES") != nullptr;
@@ -165,6 +166,8 @@ int main(int argc, char *argv[])
 	auto lap = [&](const char *what) {
 		if (phases) std::cerr << "[phase] " << what << ": " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
 	};
+	opt.inputs = inputFiles;
+	if (getenv("NTSM_NO_EARLY")) opt.early = false;        /* do not start parsing the first input while the sites load */
 	ntsm::FingerPrint fp(opt);
 	lap("sites loaded + first GPU context");
 	fp.computeCounts(inputFiles);

@@ -918,13 +918,14 @@ def test_cli_parallel_gzip_ingest(nt, tmp_path):
         base = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert base.returncode == 0, base.stderr[-400:]
         for t, chunk in (("8", "20000"), ("3", "300000"), ("16", "0")):
-            p = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", t, "-v", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                               env=dict(os.environ, NTSM_GZ_PARALLEL_MIN="1000", NTSM_GZ_CHUNK=chunk))
-            assert p.returncode == 0, p.stderr[-400:]
-            assert b"parallel gzip:" in p.stderr                        # took the parallel route
-            assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr), (name, t, chunk)
-            if name == "wrapped.fq.gz":
-                assert b"parallel gzip: sequential after" in p.stderr
+            for early in (True, False):                                 # parsed beside the start-up (early_ingest.hpp) or on the ordinary path
+                p = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", t, "-v", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                   env=dict(os.environ, NTSM_GZ_PARALLEL_MIN="1000", NTSM_GZ_CHUNK=chunk, **({} if early else {"NTSM_NO_EARLY": "1"})))
+                assert p.returncode == 0, p.stderr[-400:]
+                assert (b"early ingest (gzip" if early else b"parallel gzip:") in p.stderr     # took the parallel route
+                assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr), (name, t, chunk, early)
+                if name == "wrapped.fq.gz" and not early:
+                    assert b"parallel gzip: sequential after" in p.stderr
 
 
 def test_producer_lanes_share_one_context(nt, tmp_path):
@@ -1084,12 +1085,15 @@ def test_cli_block_parallel_single_file(nt, tmp_path):
         base = subprocess.run([exe, "-s", sites_fa] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert base.returncode == 0, base.stderr[-400:]
         for t, blk in (("4", "1048576"), ("8", "300000"), ("3", "65536")):
-            env = dict(os.environ, NTSM_BLOCK_BYTES=blk)
-            p = subprocess.run([exe, "-s", sites_fa, "-t", t, "-v"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-            assert p.returncode == 0, p.stderr[-400:]
-            assert p.stdout == base.stdout
-            assert _summary(p.stderr) == _summary(base.stderr)
-            assert b"block-parallel" in p.stderr
+            # the first file is parsed while the sites load (early_ingest.hpp: "early ingest" on stderr); NTSM_NO_EARLY=1 keeps
+            # everything on the ordinary path, whose first file then says "block-parallel"
+            for early in (True, False):
+                env = dict(os.environ, NTSM_BLOCK_BYTES=blk, **({} if early else {"NTSM_NO_EARLY": "1"}))
+                p = subprocess.run([exe, "-s", sites_fa, "-t", t, "-v"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+                assert p.returncode == 0, p.stderr[-400:]
+                assert p.stdout == base.stdout
+                assert _summary(p.stderr) == _summary(base.stderr)
+                assert (b"early ingest (plain FASTQ" in p.stderr) == early and (early and len(files) == 1 or b"block-parallel" in p.stderr)
     # after a parallel phase that stopped early a thread's staging slot is held but empty; the next file brings a read
     # larger than the slot (a multi-MB contig): the slot must grow, not overflow (small slots make it certain)
     rng = np.random.default_rng(5)

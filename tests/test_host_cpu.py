@@ -291,7 +291,7 @@ def test_block_parallel_ingest_under_tsan(nt, tmp_path):
     exe = str(tmp_path / "parallel_tsan")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
     srcs = [os.path.join(ROOT, "tools", "parallel_tsan.cpp")] + [os.path.join(host, f) for f in
-            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "inflate_spec.cpp", "gz_stream.cpp", "gz_parallel.cpp", "crc32_fast.cpp", "pack2.cpp")]
+            ("host_capi.cpp", "early_ingest.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "inflate_spec.cpp", "gz_stream.cpp", "gz_parallel.cpp", "crc32_fast.cpp", "pack2.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
     fq = str(tmp_path / "t.fq")
@@ -609,7 +609,7 @@ def test_parallel_gzip_ingest_under_tsan(nt, tmp_path):
     exe = str(tmp_path / "parallel_tsan")
     host = os.path.join(ROOT, "ntsm_amd", "csrc", "host")
     srcs = [os.path.join(ROOT, "tools", "parallel_tsan.cpp")] + [os.path.join(host, f) for f in
-            ("host_capi.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "inflate_spec.cpp", "gz_stream.cpp", "gz_parallel.cpp", "crc32_fast.cpp", "pack2.cpp")]
+            ("host_capi.cpp", "early_ingest.cpp", "parallel_fastq.cpp", "seq_reader.cpp", "site_set.cpp", "report.cpp", "inflate.cpp", "inflate_spec.cpp", "gz_stream.cpp", "gz_parallel.cpp", "crc32_fast.cpp", "pack2.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", exe] + srcs + ["-lz", "-lpthread"], check=True)
     s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
     fq = str(tmp_path / "t.fq")
@@ -629,6 +629,63 @@ def test_parallel_gzip_ingest_under_tsan(nt, tmp_path):
             assert p.returncode == 0, p.stderr.decode()[-3000:]
             outs.add(p.stdout.split(b" parallel=")[0] + b" " + p.stdout.split(b" ")[-1])
         assert len(outs) == 1, outs
+
+
+def test_early_ingest_packs_the_same_reads(nt, tmp_path):
+    """early_ingest.hpp: the first input file parsed into packed chunks in ordinary memory while the sites load.  The chunks
+    of a plain FASTQ and of the same reads as .gz hold the same reads as the sequential reader delivers: same number of reads
+    and bases, and the same multiset of maximal runs of valid bases (every read is followed by at least one invalid position,
+    so runs never join across reads) -- for strict files, a file with a wrapped record (parallel prefix + sequential rest),
+    FASTA, small chunk budgets (parsers wait for the consumers) and a read longer than a chunk."""
+    import collections
+    import re
+    from ntsm_amd.capi import early_ingest, flatten_file, gunzip_parallel_chunk
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
+    fq = str(tmp_path / "t.fq")
+    s.write_fastq(fq, 0, 40000)
+    raw = open(fq, "rb").read()
+    lines = raw.split(b"\n")
+    w = list(lines)
+    w[80001] = w[80001][:50] + b"\n" + w[80001][50:]
+    long_read = b"@long\n" + b"ACGTTGCA" * 40000 + b"\n+\n" + b"I" * 320000 + b"\n"
+    cases = {"strict.fq": raw, "wrapped.fq": b"\n".join(w),
+             "longread.fq": b"\n".join(lines[:36000]) + b"\n" + long_read + b"\n".join(lines[36000:38000]) + b"\n"}
+    tb = bytearray(b"N" * 256)
+    for letters, code in ((b"Aa\x00", b"A"), (b"Cc\x01", b"C"), (b"Gg\x02", b"G"), (b"TtUu\x03", b"T")):
+        for ch in letters:
+            tb[ch] = code[0]
+    table = bytes(tb)
+
+    def runs_of_reads(bases, ends):
+        out, st, bb = collections.Counter(), 0, bases.tobytes().translate(table)
+        for x in ends.tolist():
+            out.update(r for r in bb[st:x].split(b"N") if r)
+            st = x + 1
+        return out
+    try:
+        gunzip_parallel_chunk(30000)
+        for name, data in cases.items():
+            for gz in (False, True):
+                p = str(tmp_path / (name + (".gz" if gz else "")))
+                open(p, "wb").write(_gz_member(data, 6) if gz else data)
+                ref_b, ref_e, _ = flatten_file(p)
+                want = runs_of_reads(ref_b, ref_e)
+                for par, dec, block, chunk, budget, cons in ((4, 4, 1 << 20, 1 << 20, 64, 2), (3, 2, 200_000, 40_000, 6, 1), (6, 5, 1 << 20, 300_000, 12, 3)):
+                    r = early_ingest(p, par, dec, block, chunk, budget, cons)
+                    assert r is not None, (name, gz)
+                    text, n_reads, n_bases, n_par = r
+                    assert n_reads == len(ref_e) and n_bases == int(ref_e[-1]) + 1 - len(ref_e), (name, gz, par, n_reads, len(ref_e))
+                    assert collections.Counter(x for x in re.split(b"N+", text) if x) == want, (name, gz, par, dec, block, chunk)
+                    if name == "strict.fq":
+                        assert n_par == n_reads
+                    if name == "wrapped.fq":
+                        assert 0 < n_par < n_reads
+        fa = str(tmp_path / "x.fa")
+        open(fa, "wb").write(b"".join(b">s%d\nACGTACGTAGCTAGCTAGCTAGCATCGAT\n" % i for i in range(100000)))
+        assert early_ingest(fa) is None                                  # FASTA: not for this path (the ordinary one reads it)
+        assert early_ingest(str(tmp_path / "absent.fq")) is None
+    finally:
+        gunzip_parallel_chunk(0)
 
 
 def test_gzip_reader_paths_agree(nt, tmp_path, monkeypatch):
