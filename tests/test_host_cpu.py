@@ -629,6 +629,15 @@ def test_parallel_gzip_ingest_under_tsan(nt, tmp_path):
             assert p.returncode == 0, p.stderr.decode()[-3000:]
             outs.add(p.stdout.split(b" parallel=")[0] + b" " + p.stdout.split(b" ")[-1])
         assert len(outs) == 1, outs
+        # the early ingest on the same file (parsers -> packed chunks -> consumers, a small chunk budget so that parsers wait)
+        if name != "cut.gz":
+            outs = set()
+            for par, dec, block, cpos, budget, cons in ((4, 4, 1 << 20, 100000, 10, 3), (2, 3, 1 << 20, 1 << 20, 64, 1)):
+                p = subprocess.run([exe, path, "early", str(par), str(dec), str(block), str(cpos), str(budget), str(cons)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                   env=dict(env, NTSM_PARALLEL_CHUNK="20000"))
+                assert p.returncode == 0, p.stderr.decode()[-3000:]
+                outs.add(p.stdout)
+            assert len(outs) == 1 and b"reads=12000 " in outs.pop(), outs
 
 
 def test_early_ingest_packs_the_same_reads(nt, tmp_path):

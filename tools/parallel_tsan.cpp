@@ -12,6 +12,18 @@ int main(int argc, char **argv)
 	if (argc < 4) return 2;
 	uint8_t *bases = nullptr;
 	uint64_t *ends = nullptr, nb = 0, nr = 0, nblk = 0, npar = 0, resume = 0;
+	if (argc >= 8) {   /* parallel_tsan FILE early PARSERS DECODERS BLOCK CHUNK_POSITIONS BUDGET CONSUMERS: early_ingest.hpp */
+		uint8_t *text = nullptr;
+		uint64_t nt = 0, nreads = 0, nbases = 0, npar2 = 0;
+		int rc = ntsm_host_early_ingest(argv[1], (unsigned) atoi(argv[3]), (unsigned) atoi(argv[4]), strtoull(argv[5], nullptr, 10), strtoull(argv[6], nullptr, 10),
+				strtoull(argv[7], nullptr, 10), argc > 8 ? (unsigned) atoi(argv[8]) : 2u, &text, &nt, &nreads, &nbases, &npar2);
+		if (rc) { fprintf(stderr, "rc=%d\n", rc); return 1; }
+		uint64_t letters = 0;
+		for (uint64_t i = 0; i < nt; ++i) letters += text[i] != 'N';
+		printf("reads=%llu bases=%llu letters=%llu\n", (unsigned long long) nreads, (unsigned long long) nbases, (unsigned long long) letters);
+		ntsm_host_free(text);
+		return 0;
+	}
 	if (argc >= 6) {
 		int st = 0;
 		ntsm_host_gunzip_parallel_chunk(strtoull(argv[5], nullptr, 10));
