@@ -1,5 +1,6 @@
 #include "early_ingest.hpp"
 
+#include <sys/mman.h>
 #include <sys/stat.h>
 
 #include <chrono>
@@ -14,6 +15,22 @@
 
 namespace ntsm {
 
+PackedChunk::~PackedChunk() { free(mem); }
+
+void PackedChunk::reserve(uint64_t positions)
+{
+	if (cap >= positions) return;
+	free(mem);
+	const size_t huge = 2u << 20;
+	const size_t bytes = ((size_t) (positions / 4 + positions / 8) + huge - 1) & ~(huge - 1);
+	mem = aligned_alloc(huge, bytes);
+	if (!mem) { cap = 0; codes = valid = nullptr; return; }
+	(void) madvise(mem, bytes, MADV_HUGEPAGE);
+	codes = (uint8_t *) mem;
+	valid = codes + positions / 4;
+	cap = positions;
+}
+
 bool EarlyIngest::Sink::has_room(uint64_t len) const
 {
 	return !m_cur || pack2_extent(m_cur->pos, len) <= m_cur->cap;
@@ -25,7 +42,7 @@ void EarlyIngest::Sink::feed(const char *seq, uint64_t len)
 		m_cur = m_owner->blank(pack2_extent(0, len));
 		if (!m_cur) return;                                    /* the run is being abandoned */
 	}
-	m_cur->pos = pack2_append(m_cur->codes.get(), m_cur->valid.get(), m_cur->pos, seq, len);
+	m_cur->pos = pack2_append(m_cur->codes, m_cur->valid, m_cur->pos, seq, len);
 	m_cur->n_bases += len;
 	++m_cur->n_reads;
 	++fed;
@@ -57,11 +74,8 @@ std::unique_ptr<PackedChunk> EarlyIngest::blank(uint64_t min_positions)
 	}
 	const uint64_t want = std::max<uint64_t>(m_chunkPositions, (min_positions + 31) & ~31ull);
 	if (!c) c.reset(new PackedChunk());
-	if (c->cap < want) {
-		c->codes.reset(new uint8_t[want / 4]);
-		c->valid.reset(new uint8_t[want / 8]);
-		c->cap = want;
-	}
+	c->reserve(want);
+	if (!c->cap) return nullptr;
 	c->pos = c->n_bases = 0;
 	c->n_reads = 0;
 	return c;
@@ -96,7 +110,7 @@ bool EarlyIngest::next(std::unique_ptr<PackedChunk> *out)
 	return true;
 }
 
-EarlyIngest::EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t gz_min_bytes, uint64_t chunk_positions, size_t max_chunks)
+EarlyIngest::EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t gz_min_bytes, uint64_t chunk_positions, size_t max_chunks, int kinds)
 	: m_path(std::move(path)), m_nParsers(n_parsers ? n_parsers : 1), m_nDecoders(n_decoders ? n_decoders : 1), m_blockBytes(block_bytes),
 	  m_chunkPositions(chunk_positions & ~31ull), m_maxChunks(max_chunks < 2 * (size_t) (n_parsers ? n_parsers : 1) ? 2 * (size_t) (n_parsers ? n_parsers : 1) : max_chunks)
 {
@@ -104,10 +118,11 @@ EarlyIngest::EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decode
 	if (stat(m_path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return;
 	m_plain.reset(new ParallelFastq());
 	if (m_plain->open(m_path, m_blockBytes)) {
+		if (!(kinds & 1)) { m_plain.reset(); return; }
 		m_how = "plain FASTQ, block-parallel";
 	} else {
 		m_plain.reset();
-		if (getenv("NTSM_ZLIB_ONLY") || (uint64_t) st.st_size < gz_min_bytes || !GzStream::is_gzip(m_path)) return;
+		if (!(kinds & 2) || getenv("NTSM_ZLIB_ONLY") || (uint64_t) st.st_size < gz_min_bytes || !GzStream::is_gzip(m_path)) return;
 		GzStream::set_decoder_threads(m_nDecoders);
 		m_gz.reset(new GzStream());
 		const bool ok = m_gz->open(m_path);

@@ -170,8 +170,8 @@ void Feeder::submitChunk(const PackedChunk &c)
 	int rc = ntsm_lane_acquire_packed(m_lane, &m_codes, &m_valid, &m_capPos);
 	if (rc) die(rc, "cannot acquire staging");
 	if (m_capPos < need) die(NTSM_ERR_ARG, "staging slot smaller than an early chunk");
-	memcpy(m_codes, c.codes.get(), need / 4);
-	memcpy(m_valid, c.valid.get(), need / 8);
+	memcpy(m_codes, c.codes, need / 4);
+	memcpy(m_valid, c.valid, need / 8);
 	rc = ntsm_lane_submit_packed(m_lane, c.pos, c.n_reads, c.n_bases);
 	if (rc) die(rc, "submit failed");
 	m_codes = m_valid = nullptr;
@@ -284,11 +284,11 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 		if (m_opt.early && m_opt.pack && m_opt.threads > 1 && !maybe_armed && m_opt.verbose <= 2 && !m_opt.inputs.empty()) {
 			const unsigned n_par = std::min(m_opt.threads, 16u);
 			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-			const unsigned n_dec = m_opt.gz_decoders ? m_opt.gz_decoders : std::min(std::min(20u, hw), 2 * m_opt.threads);
+			const unsigned n_dec = m_opt.gz_decoders ? m_opt.gz_decoders : std::min(std::min(12u, hw), 2 * m_opt.threads);   /* fewer than later: the start-up has threads of its own */
 			const uint64_t chunk_pos = std::max<uint64_t>(4096, std::min<uint64_t>(std::max<uint64_t>(4096, m_opt.batch_bytes), lane_bytes(m_opt.threads))) & ~31ull;
 			const size_t max_chunks = (size_t) std::max<uint64_t>(4 * n_par, (4ull << 30) / (chunk_pos * 3 / 8 + 1));   /* 4 GiB of packed reads at most */
 			m_early.reset(new EarlyIngest(m_opt.inputs[0], n_par, n_dec, std::min<uint64_t>(m_opt.block_bytes, 2 * lane_bytes(m_opt.threads)),
-			                              m_opt.gz_parallel_min_bytes, chunk_pos, max_chunks));
+			                              m_opt.gz_parallel_min_bytes, chunk_pos, max_chunks, m_opt.early_kinds));
 			if (!m_early->taken()) m_early.reset();
 		}
 	}
@@ -440,9 +440,9 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 			const auto tp0 = std::chrono::steady_clock::now();
 			const size_t n_par = std::min<size_t>(want, 16);
 			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-			/* decoder threads: twice the feeders, at most 20 -- measured on a 2 x 64-core host (6.3 GB of text, 1 MiB chunks): 16
-			 * decoders deliver 12-13 GB/s, 32 no more than that, 64 less (they fall over each other in the memory system) */
-			unsigned n_dec = (unsigned) std::min<size_t>(std::min<size_t>(20, hw), 2 * want);
+			/* decoder threads: twice the feeders, at most 16 -- measured on a 2 x 64-core host (6.3 GB of text, 1 MiB chunks, 16
+			 * feeders): 8 / 12 / 16 / 20 / 24 / 32 decoders inflate + parse + count in 0.74 / 0.51 / 0.42 / 0.48 / 0.47 / 0.52 s */
+			unsigned n_dec = (unsigned) std::min<size_t>(std::min<size_t>(16, hw), 2 * want);
 			if (m_opt.gz_decoders) n_dec = m_opt.gz_decoders;
 			GzStream::set_decoder_threads(n_dec);
 			std::unique_ptr<GzStream> gz(new GzStream());

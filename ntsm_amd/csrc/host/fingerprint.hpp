@@ -44,6 +44,7 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	 * while the sites load and the tables build (early_ingest.hpp; NTSM_NO_EARLY=1 switches that off) */
 	std::vector<std::string> inputs;
 	bool early = true;
+	int early_kinds = 3;                   /* NTSM_EARLY=plain|gz: only that kind of first file (1 plain FASTQ, 2 gzip, 3 both) */
 };
 
 /* The staging batch one host thread is filling for a GPU context: the context's own slots (single-threaded and

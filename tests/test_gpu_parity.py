@@ -483,7 +483,7 @@ def test_random_reads_vs_oracle_n10_full(nt, tmp_path):
         ctx.submit(bases, ends)
         t = ctx.sync()
         assert np.array_equal(ctx.counts(), want), (variant, tun)
-        assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases), (variant, tun)
+        assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits), (variant, tun)   # (the oracle saw one long "read": its base count includes the terminators)
         ctx.close()
 
 
