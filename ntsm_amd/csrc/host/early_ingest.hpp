@@ -3,8 +3,8 @@
  * src/ntSeqMatchCount.cpp:175-182, covers the table build and the scan one after the other).
  *
  * A run spends its first 0.25-0.3 s loading the sites file and building / uploading the tables; nothing of that depends on
- * the reads.  With -t N (and no -m: the result then does not depend on the order of the reads) the first input file is
- * therefore opened at once and parsed by the same block-parallel machinery as later (parallel_fastq.hpp for a plain FASTQ,
+ * the reads.  With -t N (and no -m: the result then does not depend on the order of the reads) the first input file -- by
+ * default only if it is gzip, see Options::early_kinds for the measurement -- is therefore opened at once and parsed by the same block-parallel machinery as later (parallel_fastq.hpp for a plain FASTQ,
  * parallel_gz_fastq.hpp over the decoder pool for gzip), only into ordinary memory instead of pinned lane slots: every
  * parsing thread packs its reads (pack2.hpp: 2-bit codes + validity bits, 3/8 byte per position) into chunks laid out
  * exactly like a packed lane slot.  Once the context is there, the feeders copy the finished chunks into their lanes and

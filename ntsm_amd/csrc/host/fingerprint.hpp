@@ -44,7 +44,11 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	 * while the sites load and the tables build (early_ingest.hpp; NTSM_NO_EARLY=1 switches that off) */
 	std::vector<std::string> inputs;
 	bool early = true;
-	int early_kinds = 3;                   /* NTSM_EARLY=plain|gz: only that kind of first file (1 plain FASTQ, 2 gzip, 3 both) */
+	/* which kind of first file: 1 plain FASTQ, 2 gzip, 3 both (NTSM_EARLY=plain|gz|all).  Default gzip only: measured on a
+	 * 12.6 GB FASTQ, the early path parses into gigabytes of memory touched for the first time at 1/6 of the speed of the lane
+	 * slots (reused, pinned, cache-warm) and loses (0.85 s against 0.41 s whole process); a .gz, whose inflate dominates, gains
+	 * (2e7 / 4e7 reads: 0.68 / 1.22 s against 0.80 / 1.29 s) */
+	int early_kinds = 2;
 };
 
 /* The staging batch one host thread is filling for a GPU context: the context's own slots (single-threaded and

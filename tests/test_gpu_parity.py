@@ -1085,10 +1085,10 @@ def test_cli_block_parallel_single_file(nt, tmp_path):
         base = subprocess.run([exe, "-s", sites_fa] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert base.returncode == 0, base.stderr[-400:]
         for t, blk in (("4", "1048576"), ("8", "300000"), ("3", "65536")):
-            # the first file is parsed while the sites load (early_ingest.hpp: "early ingest" on stderr); NTSM_NO_EARLY=1 keeps
-            # everything on the ordinary path, whose first file then says "block-parallel"
+            # NTSM_EARLY=all: the first file is parsed while the sites load (early_ingest.hpp: "early ingest" on stderr); by default
+            # a plain file stays on the ordinary path, whose first file then says "block-parallel"
             for early in (True, False):
-                env = dict(os.environ, NTSM_BLOCK_BYTES=blk, **({} if early else {"NTSM_NO_EARLY": "1"}))
+                env = dict(os.environ, NTSM_BLOCK_BYTES=blk, **({"NTSM_EARLY": "all"} if early else {}))   # plain files are not taken early by default
                 p = subprocess.run([exe, "-s", sites_fa, "-t", t, "-v"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
                 assert p.returncode == 0, p.stderr[-400:]
                 assert p.stdout == base.stdout
