@@ -29,14 +29,14 @@ def main():
     c = median_per_dispatch(os.path.join(src, "pmc_tcc"))
     c.update(median_per_dispatch(os.path.join(src, "pmc_sq")))
     doc = {"source": "%s: rocprofv3 --pmc passes (one counter group each, no trace domains) over tools/stress_sweep.py 0:0" % os.path.basename(src.rstrip("/")),
-           "kernel_source_sha16": kernel_source_sha16(), "workload": "configs[4]: %d site 19-mers, %d reads of 150 bp" % (rate["site_kmers"], rate["reads"]),
+           "kernel_source_sha16": kernel_source_sha16(), "workload": "%d site 19-mers, %d reads of 150 bp" % (rate["site_kmers"], rate["reads"]),
            "two_level": rate["two_level"], "bloom_MiB": rate["bloom_MiB"], "site_minimizers": rate["site_minimizers"],
            "kernel_ms_unprofiled": rate["kernel_ms"], "gbases_per_s_unprofiled": rate["gbases_per_s"],
            "l2_requests_per_base": c.get("TCC_REQ_sum", 0) / bases, "l2_hits_per_base": c.get("TCC_HIT_sum", 0) / bases,
            "l2_misses_per_base": c.get("TCC_MISS_sum", 0) / bases, "fabric_read_requests_per_base": c.get("TCC_EA0_RDREQ_sum", 0) / bases,
            "valu_insts_per_position": c["SQ_INSTS_VALU"] * 64 / (bases * 151 / 150) if c.get("SQ_INSTS_VALU") else None,
            "fabric_request_rate_G_per_s": c.get("TCC_EA0_RDREQ_sum", 0) / (rate["kernel_ms"] / 1e3) / 1e9,
-           "note": "fabric (Infinity Cache / HBM) read requests are what binds this configuration: ~55-65 G/s is the measured cap for random requests that miss the L2"}
+           "note": "fabric (Infinity Cache / HBM) read requests: ~55-65 G/s is the measured cap for random requests that miss the L2"}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))
 
