@@ -194,7 +194,10 @@ int ntsm_set_armed_chunk(ntsm_ctx *ctx, uint64_t chunk_bytes);
  *   3  the tabulated k = 19 kernel, a measured negative result (7 % slower) that only exists in
  *      -DNTSM_WITH_TAB builds (`make tab`: ntsm_amd/libntsm_hip_tab.so); the default library answers NTSM_ERR_ARG.
  * One-level and two-level filters are different tables: a call that changes the level rebuilds them, and counts and
- * totals restart from zero (like ntsm_set_tuning with a filter size). */
+ * totals restart from zero (like ntsm_set_tuning with a filter size); variant 3 always counts with the one-level tables (its
+ * exotic tiles go to the one-level k = 19 kernel), so it rebuilds them on a context that had chosen two levels.
+ * A rebuild (here or in ntsm_set_tuning) that fails half way -- out of device memory -- leaves no consistent set of tables:
+ * the context is marked failed and every later call on it answers NTSM_ERR_STATE; ntsm_destroy is the only way out. */
 int ntsm_set_kernel(ntsm_ctx *ctx, int variant);
 /* Introspection for tests and profiles (implies a sync): out[0] = 64 KiB tiles the tabulated kernel handed to the
  * exact kernel because they hold bytes outside ACGTUNacgtun, out[1..3] = count launches by kernel
