@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential soak of the CLI against the CPU oracle (test tooling; uses oracle/ as the checker only):
 random site sets and k, FASTQ / FASTA / gzip / BGZF inputs with ragged reads, Ns, lower case, CRLF and wrapped
-records, random -t / -d / -m, random staging and block sizes.  stdout must be byte-identical and the summary lines
+records, random -t / -d / -m, random staging and block sizes, random thresholds / chunk sizes / decoder counts of the parallel gzip
+ingest and of the early ingest.  stdout must be byte-identical and the summary lines
 equal.   tools/soak.py [seconds] [seed]"""
 import gzip, os, random, struct, subprocess, sys, tempfile, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -87,7 +88,12 @@ while time.time() < t_end:
         args += ["-m", "%.3f" % rng.choice([0.05, 0.5, 2.0, 10.0])]
     t = rng.choice([1, 1, 2, 3, 8, 16])
     env = dict(os.environ, NTSM_BLOCK_BYTES=str(rng.choice([4096, 65536, 1 << 20, 16 << 20])),
-               NTSM_BATCH_BYTES=str(rng.choice([8192, 1 << 20, 64 << 20])))
+               NTSM_BATCH_BYTES=str(rng.choice([8192, 1 << 20, 64 << 20])),
+               # round 4: the parallel gzip ingest on files of any size, small chunks, and the early ingest of the first file
+               NTSM_GZ_PARALLEL_MIN=str(rng.choice([100, 5000, 8 << 20])), NTSM_GZ_CHUNK=str(rng.choice([1024, 4096, 50000, 0])),
+               NTSM_GZ_DECODERS=str(rng.choice([0, 2, 5])), NTSM_EARLY=rng.choice(["gz", "plain", "all"]))
+    if rng.random() < 0.3:
+        env["NTSM_NO_EARLY"] = "1"
     ref = subprocess.run([ORA] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     got = subprocess.run([EXE] + args + ["-t", str(t)] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     ok = (ref.returncode == got.returncode or (ref.returncode == 134 and got.returncode == -6)) and ref.stdout == got.stdout
@@ -96,7 +102,7 @@ while time.time() < t_end:
     if not ok:
         fails += 1
         keep = tempfile.mkdtemp(prefix="ntsm_soak_fail_", dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
-        print("MISMATCH iteration", it, "args", args, "-t", t, "env", env["NTSM_BLOCK_BYTES"], env["NTSM_BATCH_BYTES"], "rc", ref.returncode, got.returncode, "kept in", keep)
+        print("MISMATCH iteration", it, "args", args, "-t", t, "env", {k: v for k, v in env.items() if k.startswith("NTSM_")}, "rc", ref.returncode, got.returncode, "kept in", keep)
         print(got.stderr.decode()[-600:])
         for p in [sp] + files:
             subprocess.run(["cp", p, keep])
