@@ -217,3 +217,36 @@ def test_rccl_binding_resolves_every_symbol_ntsm_allreduce_calls(built):
     assert lib is not None
     for sym in ("ncclCommInitAll", "ncclGroupStart", "ncclGroupEnd", "ncclAllReduce", "ncclCommDestroy"):
         assert hasattr(lib, sym), sym
+
+
+def test_bench_helpers_pigz_like_and_gpu_count(tmp_path, monkeypatch):
+    """bench.py's tooling that runs without a GPU: the pigz-style writer of the e2e_cli_gz leg produces ONE gzip member that
+    gzip / zlib read back byte for byte (blocks joined by sync flushes, CRC-32 combined from the blocks'), and the launcher's
+    device count comes from sysfs and the *_VISIBLE_DEVICES lists, never from HIP."""
+    import gzip
+    import zlib
+    sys.path.insert(0, ROOT)
+    import bench
+    data = os.urandom(70_000) + b"@r1\nACGTACGTAGCTAGCTAGCATCGATCGATCGATCAGCTAGCTAGCTAC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" * 9000
+    src, dst = str(tmp_path / "x.fq"), str(tmp_path / "x.fq.gz")
+    open(src, "wb").write(data)
+    for block, threads in ((50_000, 4), (1 << 20, 2), (len(data), 1)):
+        n = bench.pigz_like(src, dst, block=block, threads=threads)
+        blob = open(dst, "rb").read()
+        assert n == len(blob) and gzip.decompress(blob) == data
+        d = zlib.decompressobj(31)
+        assert d.decompress(blob) == data and d.eof and d.unused_data == b""     # one member, nothing behind it
+    for a, b in ((b"", b"xyz"), (b"abc", b""), (b"abc", b"defgh"), (os.urandom(1000), os.urandom(77777))):
+        assert bench._crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    assert bench.count_gpus_without_hip() == 0                                   # this container has no /dev/kfd
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(os.path, "exists", lambda p: True if p == "/dev/kfd" else os.path.lexists(p))
+    import glob as _glob
+    real = _glob.glob
+    monkeypatch.setattr(_glob, "glob", lambda pat: ["/dev/dri/renderD128", "/dev/dri/renderD129", "/dev/dri/renderD130"] if pat.startswith("/dev/dri") else ([] if "kfd" in pat else real(pat)))
+    assert bench.count_gpus_without_hip() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus_without_hip() == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")                               # an empty list hides every device
+    assert bench.count_gpus_without_hip() == 0
