@@ -20,7 +20,7 @@ PackedChunk::~PackedChunk() { free(mem); }
 void PackedChunk::reserve(uint64_t positions)
 {
 	if (cap >= positions) return;
-	free(mem);                                                 /* (a pool chunk that is too small for one very long read is simply left behind) */
+	free(mem);
 	const size_t huge = 2u << 20;
 	const size_t bytes = ((size_t) (positions / 4 + positions / 8) + huge - 1) & ~(huge - 1);
 	mem = aligned_alloc(huge, bytes);
@@ -65,49 +65,20 @@ void EarlyIngest::Sink::discard()
 std::unique_ptr<PackedChunk> EarlyIngest::blank(uint64_t min_positions)
 {
 	std::unique_ptr<PackedChunk> c;
-	const uint64_t want = std::max<uint64_t>(m_chunkPositions, (min_positions + 31) & ~31ull);
 	{
 		std::unique_lock<std::mutex> lk(m_mu);
 		m_cv.wait(lk, [&]() { return m_abandon || m_out < m_maxChunks; });
 		if (m_abandon) return nullptr;
 		++m_out;
 		if (!m_free.empty()) { c = std::move(m_free.front()); m_free.pop_front(); }
-		else if (m_poolNext < m_poolChunks && want <= m_chunkPositions) {
-			const size_t i = m_poolNext++;                      /* next chunk of the populated pool, in the order it is populated */
-			m_cv.wait(lk, [&]() { return m_abandon || m_populated[i]; });
-			if (m_abandon) return nullptr;
-			c.reset(new PackedChunk());
-			c->codes = m_pool + i * m_poolStride;
-			c->valid = c->codes + m_chunkPositions / 4;
-			c->cap = m_chunkPositions;
-		}
 	}
+	const uint64_t want = std::max<uint64_t>(m_chunkPositions, (min_positions + 31) & ~31ull);
 	if (!c) c.reset(new PackedChunk());
 	c->reserve(want);
 	if (!c->cap) return nullptr;
 	c->pos = c->n_bases = 0;
 	c->n_reads = 0;
 	return c;
-}
-
-void EarlyIngest::populate(size_t first, size_t step)
-{
-#ifndef MADV_POPULATE_WRITE
-#define MADV_POPULATE_WRITE 23
-#endif
-	for (size_t i = first; i < m_poolChunks; i += step) {
-		{
-			std::lock_guard<std::mutex> lk(m_mu);
-			if (m_abandon) return;
-		}
-		uint8_t *p = m_pool + i * m_poolStride;
-		if (madvise(p, m_poolStride, MADV_POPULATE_WRITE) != 0) memset(p, 0, m_poolStride);
-		{
-			std::lock_guard<std::mutex> lk(m_mu);
-			m_populated[i] = 1;
-		}
-		m_cv.notify_all();
-	}
 }
 
 void EarlyIngest::publish(std::unique_ptr<PackedChunk> c)
@@ -139,7 +110,7 @@ bool EarlyIngest::next(std::unique_ptr<PackedChunk> *out)
 	return true;
 }
 
-EarlyIngest::EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t gz_min_bytes, uint64_t chunk_positions, size_t max_chunks, int kinds, bool populate_pool)
+EarlyIngest::EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t gz_min_bytes, uint64_t chunk_positions, size_t max_chunks, int kinds)
 	: m_path(std::move(path)), m_nParsers(n_parsers ? n_parsers : 1), m_nDecoders(n_decoders ? n_decoders : 1), m_blockBytes(block_bytes),
 	  m_chunkPositions(chunk_positions & ~31ull), m_maxChunks(max_chunks < 2 * (size_t) (n_parsers ? n_parsers : 1) ? 2 * (size_t) (n_parsers ? n_parsers : 1) : max_chunks)
 {
@@ -160,20 +131,6 @@ EarlyIngest::EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decode
 		m_how = "gzip, decoder pool + piece-parallel";
 	}
 	m_taken = true;
-	if (populate_pool) {
-		/* chunks the file will need: a plain FASTQ is half sequence; a .gz inflates to 4-6x its size */
-		const uint64_t seq = m_plain ? (uint64_t) st.st_size / 2 + (uint64_t) st.st_size / 16 : (uint64_t) st.st_size * 3;
-		m_poolStride = ((size_t) (m_chunkPositions / 4 + m_chunkPositions / 8) + 4095) & ~(size_t) 4095;
-		m_poolChunks = (size_t) std::min<uint64_t>(std::min<uint64_t>(m_maxChunks, (4ull << 30) / m_poolStride), seq / m_chunkPositions + 2 * m_nParsers + 4);
-		void *m = mmap(nullptr, m_poolChunks * m_poolStride, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-		if (m == MAP_FAILED) m_poolChunks = 0;
-		else {
-			m_pool = (uint8_t *) m;
-			m_populated.assign(m_poolChunks, 0);
-			const size_t n_pop = std::min<size_t>(std::max<size_t>(2, m_nParsers), 16);
-			for (size_t t = 0; t < n_pop; ++t) m_populators.emplace_back([this, t, n_pop]() { populate(t, n_pop); });
-		}
-	}
 	m_thread = std::thread([this]() { run(); });
 }
 
@@ -185,10 +142,6 @@ EarlyIngest::~EarlyIngest()
 	}
 	m_cv.notify_all();
 	if (m_thread.joinable()) m_thread.join();
-	for (auto &t : m_populators) t.join();
-	m_ready.clear();                                           /* chunks may point into the pool: gone before it */
-	m_free.clear();
-	if (m_pool) munmap(m_pool, m_poolChunks * m_poolStride);
 }
 
 void EarlyIngest::run()

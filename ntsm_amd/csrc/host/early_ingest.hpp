@@ -36,7 +36,7 @@ struct PackedChunk {                                   /* one packed batch in or
 	/* 2 MiB-aligned and advised as huge pages: a file's worth of chunks is gigabytes of memory touched for the first time,
 	 * and with 4 KiB pages the faults (580 k for a 12.6 GB FASTQ, taken by 16 threads through one mm lock) cost six times the
 	 * parsing itself -- measured 0.76 s against 0.12 s for the same file through the (reused, pinned) lane slots */
-	void *mem = nullptr;                               /* own allocation; nullptr when codes / valid point into EarlyIngest's pool */
+	void *mem = nullptr;
 	void reserve(uint64_t positions);
 	PackedChunk() = default;
 	~PackedChunk();
@@ -48,8 +48,7 @@ class EarlyIngest {
 public:
 	/* chunk_positions: capacity of a chunk (= of a feeder's packed lane slot); max_chunks: chunks that may exist at once */
 	/* kinds: 1 = plain FASTQ, 2 = gzip, 3 = both */
-	EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t gz_min_bytes, uint64_t chunk_positions, size_t max_chunks, int kinds = 3,
-	            bool populate = true);
+	EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t gz_min_bytes, uint64_t chunk_positions, size_t max_chunks, int kinds = 3);
 	~EarlyIngest();
 	EarlyIngest(const EarlyIngest &) = delete;
 	EarlyIngest &operator=(const EarlyIngest &) = delete;
@@ -96,16 +95,6 @@ private:
 	std::mutex m_mu;
 	std::condition_variable m_cv;
 	std::deque<std::unique_ptr<PackedChunk>> m_ready, m_free;
-	/* Chunk memory mapped and populated ahead of the parsers (tools/first_touch_bench.cpp: 16 threads write into memory they
-	 * touch for the first time at 9-15 GB/s on the GPU box's host, into populated memory at 110 GB/s, and populating costs
-	 * 0.12 s for 2.3 GB when it is done in one go per thread): one anonymous mapping of m_poolChunks chunks, populated by
-	 * helper threads in chunk order (MADV_POPULATE_WRITE, memset where the kernel does not know it); blank() hands them out in
-	 * that order and waits for the one it needs; past the pool, chunks are recycled or allocated as before. */
-	uint8_t *m_pool = nullptr;
-	size_t m_poolChunks = 0, m_poolStride = 0, m_poolNext = 0;
-	std::vector<char> m_populated;
-	std::vector<std::thread> m_populators;
-	void populate(size_t first, size_t step);
 	size_t m_out = 0;                                  /* chunks that exist outside m_free */
 	bool m_done = false, m_abandon = false;
 	uint64_t m_records = 0, m_parallelRecords = 0;

@@ -288,7 +288,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 			const uint64_t chunk_pos = std::max<uint64_t>(4096, std::min<uint64_t>(std::max<uint64_t>(4096, m_opt.batch_bytes), lane_bytes(m_opt.threads))) & ~31ull;
 			const size_t max_chunks = (size_t) std::max<uint64_t>(4 * n_par, (4ull << 30) / (chunk_pos * 3 / 8 + 1));   /* 4 GiB of packed reads at most */
 			m_early.reset(new EarlyIngest(m_opt.inputs[0], n_par, n_dec, std::min<uint64_t>(m_opt.block_bytes, 2 * lane_bytes(m_opt.threads)),
-			                              m_opt.gz_parallel_min_bytes, chunk_pos, max_chunks, m_opt.early_kinds, m_opt.early_populate));
+			                              m_opt.gz_parallel_min_bytes, chunk_pos, max_chunks, m_opt.early_kinds));
 			if (!m_early->taken()) m_early.reset();
 		}
 	}

@@ -49,7 +49,6 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	 * slots (reused, pinned, cache-warm) and loses (0.85 s against 0.41 s whole process); a .gz, whose inflate dominates, gains
 	 * (2e7 / 4e7 reads: 0.68 / 1.22 s against 0.80 / 1.29 s) */
 	int early_kinds = 2;
-	bool early_populate = true;            /* NTSM_EARLY_NO_POPULATE=1: no pre-populated chunk pool (A/B) */
 };
 
 /* The staging batch one host thread is filling for a GPU context: the context's own slots (single-threaded and

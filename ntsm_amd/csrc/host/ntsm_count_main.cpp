@@ -168,7 +168,6 @@ int main(int argc, char *argv[])
 	};
 	opt.inputs = inputFiles;
 	if (getenv("NTSM_NO_EARLY")) opt.early = false;        /* do not start parsing the first input while the sites load */
-	if (getenv("NTSM_EARLY_NO_POPULATE")) opt.early_populate = false;
 	if (const char *ek = getenv("NTSM_EARLY")) opt.early_kinds = !strcmp(ek, "plain") ? 1 : !strcmp(ek, "gz") ? 2 : !strcmp(ek, "all") ? 3 : opt.early_kinds;
 	ntsm::FingerPrint fp(opt);
 	lap("sites loaded + first GPU context");
