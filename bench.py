@@ -483,7 +483,7 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
     import ntsm_amd
-    from ntsm_amd.dist import merge_counts
+    from ntsm_amd.dist import check_merged, job_expectation, merge_counts
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the count path has no CPU fallback")
@@ -558,12 +558,8 @@ def run_rank(args):
         expect = (tr.total_kmers, tr.total_hits, ref.counts())
         ref.close()
         if use_dist:
-            job_vec = torch.from_numpy(expect[2].view(np.int64).copy())
-            dist.all_reduce(job_vec, op=dist.ReduceOp.SUM, group=gloo)            # CPU tensors over gloo
-            rank_info = [None] * world
-            dist.all_gather_object(rank_info, {"rank": rank, "reads": n_reads, "first_read": rank * n_reads, "kmers": int(expect[0]), "hits": int(expect[1]),
-                                               "counts_sha256": hashlib.sha256(expect[2].tobytes()).hexdigest()}, group=gloo)
-            expect_job = (sum(r["kmers"] for r in rank_info), sum(r["hits"] for r in rank_info), job_vec.numpy().view(np.uint64))
+            jk, jh, jv, rank_info = job_expectation(rank, n_reads, expect[0], expect[1], expect[2], gloo)   # CPU tensors over gloo
+            expect_job = (jk, jh, jv)
 
     for _ in range(args.warmup):
         run_step()
@@ -591,14 +587,8 @@ def run_rank(args):
         merged_totals = ctx.sync()
         merged_counts = ctx.counts()
         if expect_job is not None:
-            assert (merged_totals.total_kmers, merged_totals.total_hits) == (reps * expect_job[0], reps * expect_job[1]), \
-                "rank %d: RCCL-merged totals %r differ from %d x the host-side (gloo) sum of the ranks' generic-kernel totals %r" \
-                % (rank, (merged_totals.total_kmers, merged_totals.total_hits), reps, expect_job[:2])
-            assert merged_totals.reads_consumed == reps * world * n_reads and merged_totals.total_bases == reps * world * bases_per_step, \
-                "rank %d: merged read / base totals are not those of %d ranks" % (rank, world)
-            assert (merged_counts == expect_job[2] * np.uint64(reps)).all(), \
-                "rank %d: RCCL-merged per-k-mer counts differ from the host-side (gloo) sum of the ranks' generic-kernel counts" % rank
-            merged_checked = True
+            merged_checked = check_merged(rank, world, reps, (merged_totals.total_kmers, merged_totals.total_hits, merged_totals.total_bases, merged_totals.reads_consumed),
+                                          merged_counts, expect_job, n_reads, bases_per_step)
         ctx.set_max_hits(0, armed=False)                   # drop the merged view: this context's own counts again
     totals = ctx.sync()
     if expect is not None:

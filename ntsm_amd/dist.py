@@ -53,6 +53,40 @@ def merge_counts(ctx, group=None, times=None):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# Proof of a merge (bench.py's N > 1 line): the job-wide expectation is formed over a route that shares nothing with the
+# collective being checked -- CPU tensors through a gloo group, totals and digests by all_gather_object -- and the merged
+# view every rank holds must equal reps x that.
+# ---------------------------------------------------------------------------------------------------------
+def job_expectation(rank, n_reads, kmers, hits, counts, gloo_group):
+    """(sum of kmers, sum of hits, host-side SUM of the ranks' count vectors as uint64 numpy, [per-rank info dicts]).
+    `counts`: this rank's expected per-k-mer counts for ONE pass over its shard (uint64 numpy), from a kernel other than the
+    one whose merge is being checked."""
+    import hashlib
+    import numpy as np
+    world = dist.get_world_size(gloo_group)
+    vec = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.uint64).view(np.int64).copy())
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=gloo_group)
+    infos = [None] * world
+    dist.all_gather_object(infos, {"rank": rank, "reads": int(n_reads), "first_read": rank * int(n_reads), "kmers": int(kmers), "hits": int(hits),
+                                   "counts_sha256": hashlib.sha256(np.ascontiguousarray(counts, dtype=np.uint64).tobytes()).hexdigest()}, group=gloo_group)
+    return sum(r["kmers"] for r in infos), sum(r["hits"] for r in infos), vec.numpy().view(np.uint64), infos
+
+
+def check_merged(rank, world, reps, merged, merged_counts, expect_job, reads_per_rank, bases_per_rank):
+    """Raises AssertionError unless the merged view (total_kmers, total_hits, total_bases, reads_consumed) + per-k-mer counts a
+    rank holds after `reps` merged passes equals reps x the job-wide expectation of job_expectation()."""
+    import numpy as np
+    kmers, hits, bases, reads = merged
+    assert (kmers, hits) == (reps * expect_job[0], reps * expect_job[1]), \
+        "rank %d: merged totals %r differ from %d x the host-side (gloo) sum of the ranks' expectations %r" % (rank, (kmers, hits), reps, tuple(expect_job[:2]))
+    assert reads == reps * world * reads_per_rank and bases == reps * world * bases_per_rank, \
+        "rank %d: merged read / base totals are not those of %d ranks" % (rank, world)
+    assert np.array_equal(np.asarray(merged_counts, dtype=np.uint64), expect_job[2] * np.uint64(reps)), \
+        "rank %d: merged per-k-mer counts differ from the host-side (gloo) sum of the ranks' expected counts" % rank
+    return True
+
+
+# ---------------------------------------------------------------------------------------------------------
 # Ordered -m early stop across ranks (SURVEY.md section 8(f) item 2)
 #
 # The reference stops after the first read at which the cumulative number of site-k-mer hits exceeds

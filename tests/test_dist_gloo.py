@@ -250,3 +250,61 @@ def test_bench_helpers_pigz_like_and_gpu_count(tmp_path, monkeypatch):
     assert bench.count_gpus_without_hip() == 2
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")                               # an empty list hides every device
     assert bench.count_gpus_without_hip() == 0
+
+
+def _proof_worker(rank, world, port, q, corrupt_rank):
+    """One rank of bench.py's merge proof with the oracle as the counting engine: `reps` passes over the rank's shard, merged
+    by allreduce_sum_ over the default group (the route under test: RCCL on the GPU box, gloo here), checked against
+    job_expectation() over a SEPARATE gloo group + check_merged().  corrupt_rank >= 0: that rank's contribution to the merge is
+    off by one in one counter -- every rank must notice."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(backend="gloo")
+    from oracle_binding import OracleFP
+    import ntsm_amd
+    from ntsm_amd.dist import allreduce_sum_, check_merged, job_expectation
+    bases, ends, _ = ntsm_amd.flatten_file(os.path.join(G, "reads2k.fq"))
+    per = 700                                              # equal shards (weak scaling: every rank owns `per` reads)
+    lo, hi = rank * per, (rank + 1) * per
+    start = 0 if lo == 0 else int(ends[lo - 1]) + 1
+    shard, shard_ends = bases[start:int(ends[hi - 1]) + 1], ends[lo:hi] - np.uint64(start)
+    fp = OracleFP(os.path.join(G, "sites200.fa"))
+    fp.process_flat(shard, shard_ends)
+    one = (fp.total_kmers, fp.total_hits, fp.kmers()[2].copy())
+    expect = job_expectation(rank, per, one[0], one[1], one[2], side)
+    reps, shard_bases = 3, int(shard.size) - per
+    local = np.concatenate([one[2] * np.uint64(reps), np.array([one[0] * reps, one[1] * reps, shard_bases * reps, per * reps], dtype=np.uint64)])
+    if rank == corrupt_rank:
+        local[5] += np.uint64(1)
+    vec = torch.from_numpy(local.view(np.int64).copy())
+    allreduce_sum_(vec)
+    m = vec.numpy().view(np.uint64)
+    try:
+        ok = check_merged(rank, world, reps, (int(m[-4]), int(m[-3]), int(m[-2]), int(m[-1])), m[:-4], expect[:3], per, shard_bases)
+        q.put((rank, "ok" if ok else "?", [r["counts_sha256"] for r in expect[3]], int(expect[0])))
+    except AssertionError as e:
+        q.put((rank, "caught: " + str(e)[:60], None, None))
+    dist.destroy_process_group()
+
+
+def test_bench_merge_proof_under_gloo(built):
+    """bench.py's N > 1 self-check (ntsm_amd.dist.job_expectation + check_merged) with two CPU ranks: a correct SUM merge of
+    three passes passes on both ranks with the ranks' digests gathered; a merge in which one rank's vector is off by one in
+    one counter is caught on BOTH ranks."""
+    ctx = mp.get_context("spawn")
+    for corrupt in (-1, 1):
+        q = ctx.Queue()
+        port = 31500 + (os.getpid() + 7 * (corrupt + 2)) % 2000
+        procs = [ctx.Process(target=_proof_worker, args=(r, 2, port, q, corrupt)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        if corrupt < 0:
+            assert [g[1] for g in got] == ["ok", "ok"] and got[0][2] == got[1][2] and len(set(got[0][2])) == 2 and got[0][3] > 0, got
+        else:
+            assert all(g[1].startswith("caught: rank %d: merged per-k-mer counts differ" % g[0]) for g in got), got
