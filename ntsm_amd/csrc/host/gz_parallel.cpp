@@ -132,7 +132,9 @@ void GzStream::Parallel::decode_chunk(Chunk &c, SpecInflate &sp)
 		for (;;) {
 			st = sp.run16(c.sym.data(), &out, c.sym.size() - kSymSlack);
 			if (st != Inflate::MORE) break;
-			if (c.sym.size() > (1ull << 30)) { st = Inflate::DATA_ERROR; break; }      /* 2 GiB of symbols from one chunk: give it to the in-order decoder */
+			/* a chunk that inflates to more than 64 times its size (text: 4-8 times) is left to the in-order decoder, which
+			 * streams in 1 MiB pieces: 16 workers must not each hold gigabytes of symbols of a pathological member */
+			if (c.sym.size() >= kWin + 64 * m_chunkBytes) { c.sym.resize(kWin + 4 * m_chunkBytes + kSymSlack); c.sym.shrink_to_fit(); SpecInflate::fill_markers(c.sym.data()); return; }
 			c.sym.resize(c.sym.size() * 2);
 		}
 		g_ns_decode += now_ns() - t1;

@@ -466,6 +466,12 @@ def test_parallel_gzip_decoder_matches_zlib(nt, tmp_path):
         raw = open(fqp, "rb").read()
         open(p, "wb").write(_gz_member(raw, 6))
         assert gunzip(p, 4, 1 << 20) == (raw, 0) and gunzip_parallel_stats()[0] >= 2
+        # a member that inflates a thousandfold: chunks give up at 64 times their size, the in-order decoder does it all
+        zeros = b"\x00" * (64 << 20)
+        open(p, "wb").write(_gz_member(zeros, 6))
+        gunzip_parallel_chunk(8192)
+        got, rc = gunzip(p, 4, 1 << 20)
+        assert rc == 0 and got == zeros and gunzip_parallel_stats()[0] == 0 and gunzip_parallel_stats()[1] > 0
     finally:
         gunzip_parallel_chunk(0)
 
