@@ -487,6 +487,36 @@ def test_random_reads_vs_oracle_n10_full(nt, tmp_path):
         ctx.close()
 
 
+def test_large_site_set_without_a_two_level_form(nt, tmp_path):
+    """k = 14 has no 14-mer minimizers, so a big site set stays on the one-level form whatever its size -- with a filter that
+    keeps growing at >= 12 bits per key instead of saturating at the 3 MiB cap that only makes sense where two levels can take
+    over.  250,000 sites = 2.4 M site 14-mers (13.5 bits per key would be 3.9 MiB): counts of 60k reads equal the oracle's for the automatic choice,
+    the forced one-level form and the generic kernel; forcing two levels is refused for this k."""
+    path = str(tmp_path / "k14.fa")
+    s = nt.SynthShort(sites_seed=31337, n_sites=250_000, k=14, read_seed=4, p_embed=0.3, sites_path=path)
+    sites = nt.Sites(path, k=14)
+    assert len(sites.keys) == s.n_kmers > 2_000_000
+    n = 60_000
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(path, k=14)
+    fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)
+    want = fp.kmers()[2]
+    assert fp.total_hits > 50_000
+    for variant in (0, 2, 1):
+        ctx = nt.Context(sites.keys, k=14)
+        ctx.set_kernel(variant)
+        assert ctx.debug_stats()["two_level"] is False
+        ctx.submit(bases, ends)
+        t = ctx.sync()
+        assert np.array_equal(ctx.counts(), want), variant
+        assert (t.total_kmers, t.total_hits) == (fp.total_kmers, fp.total_hits), variant
+        ctx.close()
+    ctx = nt.Context(sites.keys, k=14)
+    with pytest.raises(nt.NtsmError):
+        ctx.set_kernel(4)
+    ctx.close()
+
+
 def test_merge_counts_single_rank_roundtrip(nt, n10):
     """The RCCL merge plumbing on one rank: the library's device vector wrapped zero-copy as a torch tensor,
     imported back, reports the same counts/totals (ntsm_counts_device / ntsm_import_reduced)."""
