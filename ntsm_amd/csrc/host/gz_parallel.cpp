@@ -185,6 +185,7 @@ void GzStream::Parallel::worker()
 		pc->crc = crc32_fast(0, pc->data.data(), n);
 		if (!ok) pc->status = -1;                             /* cannot happen: the splice requires a full window */
 		g_ns_resolve += now_ns() - tr;
+		GzStream::release_input(m_base + r.chunk->index * m_chunkBytes, m_base + std::min<size_t>((r.chunk->index + 1) * m_chunkBytes, (size_t) (m_end - m_base)));
 		{
 			std::lock_guard<std::mutex> lk(m_mu);
 			m_bufPool.push_back(std::move(r.chunk->sym));

@@ -7,6 +7,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -161,6 +162,18 @@ bool GzStream::push(std::unique_ptr<Piece> p)
 	lk.unlock();
 	m_cv.notify_all();
 	return true;
+}
+
+/* Compressed bytes [lo, hi) of the mapped input have been decoded: drop their page-table entries now, from the worker that is
+ * done with them (the page cache keeps the data; a late reader -- the in-order decoder after a dropped chunk -- only faults
+ * them back in).  Left mapped, a 2 GB input is half a million entries that the kernel tears down single-threaded when the
+ * process exits: 0.15 s of wall time after `Time:` has been printed.  NTSM_KEEP_MAPPED=1 turns it off (measurement). */
+void GzStream::release_input(const uint8_t *lo, const uint8_t *hi)
+{
+	static const bool keep = getenv("NTSM_KEEP_MAPPED") != nullptr;
+	if (keep) return;
+	const uintptr_t a = ((uintptr_t) lo + 4095u) & ~(uintptr_t) 4095u, b = (uintptr_t) hi & ~(uintptr_t) 4095u;
+	if (b > a) madvise((void *) a, b - a, MADV_DONTNEED);
 }
 
 /* decoder thread */
@@ -322,6 +335,7 @@ const uint8_t *GzStream::produce_bgzf(const uint8_t *p, unsigned n_threads)
 				member_begin = m.trailer + 8;
 			}
 			d.piece->len = at;
+			if (!d.failed) release_input(g.begin, member_begin);
 			{
 				std::lock_guard<std::mutex> lk(mu);
 				done.emplace(g.id, std::move(d));

@@ -52,6 +52,8 @@ public:
 	static void set_parallel_chunk(size_t bytes);
 	/* what the most recently finished parallel decode did (process-wide, for tests and -v): chunks spliced / dropped */
 	static void last_parallel_stats(uint64_t out[2]);
+	/* workers: the compressed bytes [lo, hi) of the mapping are decoded (drops their page-table entries, see gz_stream.cpp) */
+	static void release_input(const uint8_t *lo, const uint8_t *hi);
 	bool open(const std::string &path);
 	int read(void *dst, unsigned len);
 	void close();
