@@ -23,12 +23,12 @@ inline uint32_t symbol_entry(Kind kind, int sym, int nbits)
 	if (kind == PRECODE) return ((uint32_t) sym << 16) | (uint32_t) nbits;
 	if (kind == DIST) {
 		if (sym >= 30) return F_ERR | (uint32_t) nbits;
-		return ((uint32_t) kDistBase[sym] << 16) | ((uint32_t) kDistExtra[sym] << 8) | (uint32_t) nbits;
+		return ((uint32_t) kDistBase[sym] << 16) | ((uint32_t) kDistExtra[sym] << 8) | (uint32_t) (nbits + kDistExtra[sym]);
 	}
 	if (sym < 256) return ((uint32_t) sym << 16) | F_LIT | (uint32_t) nbits;
 	if (sym == 256) return F_EOB | (uint32_t) nbits;
 	if (sym >= 286) return F_ERR | (uint32_t) nbits;
-	return ((uint32_t) kLenBase[sym - 257] << 16) | ((uint32_t) kLenExtra[sym - 257] << 8) | (uint32_t) nbits;
+	return ((uint32_t) kLenBase[sym - 257] << 16) | ((uint32_t) kLenExtra[sym - 257] << 8) | (uint32_t) (nbits + kLenExtra[sym - 257]);
 }
 
 inline uint32_t reverse_bits(uint32_t c, int len)
@@ -235,19 +235,22 @@ NTSM_INFLATE_CLONES Inflate::Status Inflate::run_huffman(uint8_t *buf, size_t *o
 			bb |= load64(in) << bc;
 			in += (63 - bc) >> 3;
 			bc |= 56;
+			/* One shift per symbol: a length / distance entry counts its extra bits in (e & 31), the value of the extra bits
+			 * is cut out of the copy `sv` off the critical path (table lookup -> shift -> next lookup). */
+			uint64_t sv;
 			uint32_t e = m_lit[bb & lmask];
 			if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
-			bb >>= (e & 31u); bc -= (e & 31u);
+			sv = bb; bb >>= (e & 31u); bc -= (e & 31u);
 			if (e & F_LIT) {
 				*op++ = (uint8_t) (e >> 16);
 				e = m_lit[bb & lmask];
 				if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
-				bb >>= (e & 31u); bc -= (e & 31u);
+				sv = bb; bb >>= (e & 31u); bc -= (e & 31u);
 				if (e & F_LIT) {
 					*op++ = (uint8_t) (e >> 16);
 					e = m_lit[bb & lmask];
 					if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
-					bb >>= (e & 31u); bc -= (e & 31u);
+					sv = bb; bb >>= (e & 31u); bc -= (e & 31u);
 					if (e & F_LIT) { *op++ = (uint8_t) (e >> 16); continue; }
 				}
 			}
@@ -257,18 +260,20 @@ NTSM_INFLATE_CLONES Inflate::Status Inflate::run_huffman(uint8_t *buf, size_t *o
 				return STREAM_END;
 			}
 			const unsigned lx = (e >> 8) & 15u;
-			const uint32_t len = (e >> 16) + (uint32_t) (bb & ((1u << lx) - 1));
-			bb >>= lx; bc -= lx;
-			bb |= load64(in) << bc;
-			in += (63 - bc) >> 3;
-			bc |= 56;
+			const uint32_t len = (e >> 16) + (uint32_t) ((sv >> ((e & 31u) - lx)) & ((1u << lx) - 1));
+			/* the refill at the top (>= 56 bits) covers two literals and a length (15 + 15 + 20 bits at most); a distance
+			 * needs up to 15 + 13 more */
+			if (bc < 28u) {
+				bb |= load64(in) << bc;
+				in += (63 - bc) >> 3;
+				bc |= 56;
+			}
 			uint32_t d = m_dist[bb & dmask];
 			if (d & F_SUB) { bb >>= kDistBits; bc -= kDistBits; d = m_dist[(d >> 16) + (uint32_t) (bb & ((1u << ((d >> 8) & 15u)) - 1))]; }
-			bb >>= (d & 31u); bc -= (d & 31u);
+			sv = bb; bb >>= (d & 31u); bc -= (d & 31u);
 			if (d & F_ERR) { SAVE(); return DATA_ERROR; }
 			const unsigned dx = (d >> 8) & 15u;
-			const uint32_t dist = (d >> 16) + (uint32_t) (bb & ((1u << dx) - 1));
-			bb >>= dx; bc -= dx;
+			const uint32_t dist = (d >> 16) + (uint32_t) ((sv >> ((d & 31u) - dx)) & ((1u << dx) - 1));
 			if ((uint64_t) dist > total0 + (uint64_t) (op - op0)) { SAVE(); return DATA_ERROR; }   /* "invalid distance too far back" */
 			const uint8_t *src = op - dist;
 			uint8_t *const end = op + len;
@@ -292,12 +297,12 @@ NTSM_INFLATE_CLONES Inflate::Status Inflate::run_huffman(uint8_t *buf, size_t *o
 			bb >>= kLitBits; bc -= kLitBits;
 			e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))];
 		}
-		if ((e & 31u) > bc || ((e & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
+		const unsigned lx = (e >> 8) & 15u, nb = (e & 31u) - lx;     /* extra bits (0 unless a length), bits of the code itself */
+		if (nb > bc || ((e & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
 		if (e & F_ERR) { st = DATA_ERROR; break; }
-		bb >>= (e & 31u); bc -= (e & 31u);
+		bb >>= nb; bc -= nb;
 		if (e & F_LIT) { *op++ = (uint8_t) (e >> 16); continue; }
 		if (e & F_EOB) { st = STREAM_END; break; }
-		const unsigned lx = (e >> 8) & 15u;
 		if (bc < lx) { st = TRUNCATED; break; }
 		const uint32_t len = (e >> 16) + (uint32_t) (bb & ((1u << lx) - 1));
 		bb >>= lx; bc -= lx;
@@ -308,10 +313,10 @@ NTSM_INFLATE_CLONES Inflate::Status Inflate::run_huffman(uint8_t *buf, size_t *o
 			bb >>= kDistBits; bc -= kDistBits;
 			d = m_dist[(d >> 16) + (uint32_t) (bb & ((1u << ((d >> 8) & 15u)) - 1))];
 		}
-		if ((d & 31u) > bc || ((d & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
+		const unsigned dx = (d >> 8) & 15u, db = (d & 31u) - dx;
+		if (db > bc || ((d & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
 		if (d & F_ERR) { st = DATA_ERROR; break; }
-		bb >>= (d & 31u); bc -= (d & 31u);
-		const unsigned dx = (d >> 8) & 15u;
+		bb >>= db; bc -= db;
 		if (bc < dx) { st = TRUNCATED; break; }
 		const uint32_t dist = (d >> 16) + (uint32_t) (bb & ((1u << dx) - 1));
 		bb >>= dx; bc -= dx;

@@ -11,6 +11,7 @@ namespace ntsm {
 namespace {
 inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 inline void store64(void *p, uint64_t v) { memcpy(p, &v, 8); }
+inline void copy16(void *dst, const void *src) { unsigned char t[16]; memcpy(t, src, 16); memcpy(dst, t, 16); }
 } // namespace
 
 void SpecInflate::fill_markers(uint16_t *sym)
@@ -81,19 +82,22 @@ NTSM_INFLATE_CLONES Inflate::Status SpecInflate::run_huffman16(uint16_t *buf, si
 			bb |= load64(in) << bc;
 			in += (63 - bc) >> 3;
 			bc |= 56;
+			/* One shift per symbol: a length / distance entry counts its extra bits in (e & 31), the value of the extra bits
+			 * is cut out of the copy `sv` off the critical path (table lookup -> shift -> next lookup). */
+			uint64_t sv;
 			uint32_t e = m_lit[bb & lmask];
 			if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
-			bb >>= (e & 31u); bc -= (e & 31u);
+			sv = bb; bb >>= (e & 31u); bc -= (e & 31u);
 			if (e & F_LIT) {
 				*op++ = (uint16_t) (e >> 16);
 				e = m_lit[bb & lmask];
 				if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
-				bb >>= (e & 31u); bc -= (e & 31u);
+				sv = bb; bb >>= (e & 31u); bc -= (e & 31u);
 				if (e & F_LIT) {
 					*op++ = (uint16_t) (e >> 16);
 					e = m_lit[bb & lmask];
 					if (e & F_SUB) { bb >>= kLitBits; bc -= kLitBits; e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))]; }
-					bb >>= (e & 31u); bc -= (e & 31u);
+					sv = bb; bb >>= (e & 31u); bc -= (e & 31u);
 					if (e & F_LIT) { *op++ = (uint16_t) (e >> 16); continue; }
 				}
 			}
@@ -102,22 +106,31 @@ NTSM_INFLATE_CLONES Inflate::Status SpecInflate::run_huffman16(uint16_t *buf, si
 				return (e & F_ERR) ? DATA_ERROR : STREAM_END;
 			}
 			const unsigned lx = (e >> 8) & 15u;
-			const uint32_t len = (e >> 16) + (uint32_t) (bb & ((1u << lx) - 1));
-			bb >>= lx; bc -= lx;
-			bb |= load64(in) << bc;
-			in += (63 - bc) >> 3;
-			bc |= 56;
+			const uint32_t len = (e >> 16) + (uint32_t) ((sv >> ((e & 31u) - lx)) & ((1u << lx) - 1));
+			/* the refill at the top (>= 56 bits) covers two literals and a length (15 + 15 + 20 bits at most); a distance
+			 * needs up to 15 + 13 more */
+			if (bc < 28u) {
+				bb |= load64(in) << bc;
+				in += (63 - bc) >> 3;
+				bc |= 56;
+			}
 			uint32_t d = m_dist[bb & dmask];
 			if (d & F_SUB) { bb >>= kDistBits; bc -= kDistBits; d = m_dist[(d >> 16) + (uint32_t) (bb & ((1u << ((d >> 8) & 15u)) - 1))]; }
-			bb >>= (d & 31u); bc -= (d & 31u);
+			sv = bb; bb >>= (d & 31u); bc -= (d & 31u);
 			if (d & F_ERR) { SAVE(); return DATA_ERROR; }
 			const unsigned dx = (d >> 8) & 15u;
-			const uint32_t dist = (d >> 16) + (uint32_t) (bb & ((1u << dx) - 1));
-			bb >>= dx; bc -= dx;
+			const uint32_t dist = (d >> 16) + (uint32_t) ((sv >> ((d & 31u) - dx)) & ((1u << dx) - 1));
 			/* dist <= 32768 always lands inside the buffer: its first kWindow symbols are the markers */
 			const uint16_t *src = op - dist;
 			uint16_t *const end = op + len;
-			if (dist >= 4) {
+			if (dist >= 8) {
+				/* 8 symbols at a time; DNA text is mostly matches of 6-9 symbols, which this takes without a loop */
+				copy16(op, src);
+				if (len > 8) {
+					op += 8; src += 8;
+					do { copy16(op, src); op += 8; src += 8; } while (op < end);
+				}
+			} else if (dist >= 4) {
 				do { store64(op, load64((const uint8_t *) src)); op += 4; src += 4; } while (op < end);
 			} else if (dist == 1) {
 				const uint64_t v = 0x0001000100010001ull * *src;
@@ -136,12 +149,12 @@ NTSM_INFLATE_CLONES Inflate::Status SpecInflate::run_huffman16(uint16_t *buf, si
 			bb >>= kLitBits; bc -= kLitBits;
 			e = m_lit[(e >> 16) + (uint32_t) (bb & ((1u << ((e >> 8) & 15u)) - 1))];
 		}
-		if ((e & 31u) > bc || ((e & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
+		const unsigned lx = (e >> 8) & 15u, nb = (e & 31u) - lx;     /* extra bits (0 unless a length), bits of the code itself */
+		if (nb > bc || ((e & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
 		if (e & F_ERR) { st = DATA_ERROR; break; }
-		bb >>= (e & 31u); bc -= (e & 31u);
+		bb >>= nb; bc -= nb;
 		if (e & F_LIT) { *op++ = (uint16_t) (e >> 16); continue; }
 		if (e & F_EOB) { st = STREAM_END; break; }
-		const unsigned lx = (e >> 8) & 15u;
 		if (bc < lx) { st = TRUNCATED; break; }
 		const uint32_t len = (e >> 16) + (uint32_t) (bb & ((1u << lx) - 1));
 		bb >>= lx; bc -= lx;
@@ -152,10 +165,10 @@ NTSM_INFLATE_CLONES Inflate::Status SpecInflate::run_huffman16(uint16_t *buf, si
 			bb >>= kDistBits; bc -= kDistBits;
 			d = m_dist[(d >> 16) + (uint32_t) (bb & ((1u << ((d >> 8) & 15u)) - 1))];
 		}
-		if ((d & 31u) > bc || ((d & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
+		const unsigned dx = (d >> 8) & 15u, db = (d & 31u) - dx;
+		if (db > bc || ((d & F_ERR) && in == m_end && bc < 15)) { st = TRUNCATED; break; }
 		if (d & F_ERR) { st = DATA_ERROR; break; }
-		bb >>= (d & 31u); bc -= (d & 31u);
-		const unsigned dx = (d >> 8) & 15u;
+		bb >>= db; bc -= db;
 		if (bc < dx) { st = TRUNCATED; break; }
 		const uint32_t dist = (d >> 16) + (uint32_t) (bb & ((1u << dx) - 1));
 		bb >>= dx; bc -= dx;
