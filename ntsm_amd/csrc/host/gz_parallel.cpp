@@ -181,8 +181,9 @@ void GzStream::Parallel::worker()
 		Piece *pc = r.piece;
 		const size_t n = r.chunk->n_sym;
 		const uint64_t tr = now_ns();
-		const bool ok = SpecInflate::resolve(r.chunk->sym.data() + kWin, n, r.window.data(), kWin, pc->data.data());
-		pc->crc = crc32_fast(0, pc->data.data(), n);
+		uint32_t crc = 0;
+		const bool ok = SpecInflate::resolve(r.chunk->sym.data() + kWin, n, r.window.data(), kWin, pc->data.data(), &crc);
+		pc->crc = crc;
 		if (!ok) pc->status = -1;                             /* cannot happen: the splice requires a full window */
 		g_ns_resolve += now_ns() - tr;
 		GzStream::release_input(m_base + r.chunk->index * m_chunkBytes, m_base + std::min<size_t>((r.chunk->index + 1) * m_chunkBytes, (size_t) (m_end - m_base)));

@@ -1,5 +1,7 @@
 #include "inflate_spec.hpp"
 
+#include "crc32_fast.hpp"
+
 #include <algorithm>
 #include <cstring>
 #if defined(__x86_64__)
@@ -27,24 +29,44 @@ uint64_t SpecInflate::find(const uint8_t *base, const uint8_t *end, uint64_t fro
 	const uint64_t size_bits = (uint64_t) (end - base) * 8u;
 	if (size_bits < 20 * 8) return ~0ull;
 	const uint64_t last = std::min<uint64_t>(to_bit, size_bits - 18 * 8);    /* two 64-bit loads stay inside the input */
-	for (uint64_t b = from_bit; b < last; ++b) {
+	static const struct K4 {
+		uint16_t v[4096];
+		K4() { for (unsigned i = 0; i < 4096; ++i) { unsigned k = 0, u = 0; for (unsigned j = 0; j < 4; ++j) { const unsigned l = (i >> (3 * j)) & 7u; if (l) { k += 128u >> l; ++u; } } v[i] = (uint16_t) (k | (u << 10)); } }
+	} k4_table;
+	const uint16_t *const k4 = k4_table.v;
+	/* The first 13 bits of a candidate for 44 bit offsets at a time, with word operations on w = the 64 bits from offset g:
+	 * bit i of `cand` is set iff bits i .. i+2 read 0, 0, 1 (BFINAL = 0, BTYPE = 10b), bits i+4 .. i+7 are not all ones
+	 * (HLIT <= 29) and bits i+9 .. i+12 are not all ones (HDIST <= 29).  One offset in nine survives on random data. */
+	uint64_t g = from_bit, cand = 0;
+	for (;;) {
+		while (!cand) {
+			if (g >= last) return ~0ull;
+			const uint64_t w = load64(base + (g >> 3)) >> (g & 7u);            /* >= 57 valid bits: offsets g .. g+43 have their 13 */
+			uint64_t m = ~w & ~(w >> 1) & (w >> 2);
+			m &= ~((w >> 4) & (w >> 5) & (w >> 6) & (w >> 7));
+			m &= ~((w >> 9) & (w >> 10) & (w >> 11) & (w >> 12));
+			const uint64_t span = std::min<uint64_t>(44, last - g);
+			cand = m & ((1ull << span) - 1u);
+			if (!cand) g += span;
+		}
+		const unsigned t = (unsigned) __builtin_ctzll(cand);
+		cand &= cand - 1;
+		const uint64_t b = g + t;
+		if (!cand) g += std::min<uint64_t>(44, last - g);                     /* the word is used up: the next one starts behind it */
 		const uint8_t *p = base + (b >> 3);
 		const unsigned sh = (unsigned) (b & 7u);
 		const uint64_t x = load64(p) >> sh;                                   /* >= 57 valid bits */
-		if ((x & 7u) != 4u) continue;                                         /* BFINAL = 0, BTYPE = 10b */
-		if (((x >> 3) & 31u) > 29u || ((x >> 8) & 31u) > 29u) continue;
 		const unsigned ncode = (unsigned) ((x >> 13) & 15u) + 4u;
 		/* precode lengths: 3 bits each from bit 17 of the candidate, up to 19 of them (bits 17 .. 73).  x holds the first 13
 		 * (bits 17 .. 55): most false candidates are over-subscribed by then (a random length adds 16 of the 128 on average). */
 		unsigned kraft = 0, used = 0;
 		{
-			uint64_t z = x >> 17;
+			/* four lengths (12 bits) per table look-up: Kraft sum in the low 10 bits, number of non-zero lengths above */
 			const unsigned n13 = ncode < 13u ? ncode : 13u;
-			for (unsigned i = 0; i < n13; ++i) {
-				const unsigned l = (unsigned) z & 7u;
-				z >>= 3;
-				if (l) { kraft += 128u >> l; ++used; }
-			}
+			const uint64_t z = (x >> 17) & ((1ull << (3u * n13)) - 1u);
+			const unsigned q = (unsigned) k4[z & 4095u] + k4[(z >> 12) & 4095u] + k4[(z >> 24) & 4095u] + k4[z >> 36];
+			kraft = q & 1023u;
+			used = q >> 10;
 			if (kraft > 128u) continue;
 			if (ncode > 13u) {
 				unsigned __int128 w = ((((unsigned __int128) load64(p + 8)) << 64) | load64(p)) >> (sh + 17 + 39);
@@ -243,35 +265,75 @@ inline void table_run(const uint8_t *lut, const uint16_t *sym, size_t n, uint8_t
 	for (; i < n; ++i) out[i] = lut[sym[i]];
 }
 #if defined(__x86_64__)
+/* 32 symbols at a time where they have one of the two shapes that make up almost all of a FASTQ chunk: 32 literals (a pack),
+ * or 32 CONSECUTIVE table indices s, s + 1, ... -- a stretch of one copy out of the window, i.e. 32 bytes of the window in
+ * order (a quality or header line that is a copy of a copy ... of a line in front of the chunk): one 32-byte load from the
+ * table at s.  Anything else takes 8 symbols through the table and tries again from there, so a shape that starts in the
+ * middle of a group is picked up 8 symbols later at most.  lut must be readable up to 65536 + 31. */
 __attribute__((target("avx2"))) void resolve_avx2(const uint8_t *lut, const uint16_t *sym, size_t n, uint8_t *out)
 {
-	/* groups of 32 literals go through a pack, everything else through the table */
 	const __m256i hi = _mm256_set1_epi16((short) 0xFF00);
+	const __m256i iota_a = _mm256_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+	const __m256i iota_b = _mm256_setr_epi16(16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
 	size_t i = 0;
-	for (; i + 32 <= n; i += 32) {
+	while (i + 32 <= n) {
 		const __m256i a = _mm256_loadu_si256((const __m256i *) (sym + i));
 		const __m256i b = _mm256_loadu_si256((const __m256i *) (sym + i + 16));
-		if (_mm256_testz_si256(_mm256_or_si256(a, b), hi))
+		if (_mm256_testz_si256(_mm256_or_si256(a, b), hi)) {
 			_mm256_storeu_si256((__m256i *) (out + i), _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8));
-		else
-			table_run(lut, sym + i, 32, out + i);
+			i += 32;
+			continue;
+		}
+		const __m256i first = _mm256_set1_epi16((short) sym[i]);
+		const __m256i da = _mm256_xor_si256(_mm256_sub_epi16(a, iota_a), first), db = _mm256_xor_si256(_mm256_sub_epi16(b, iota_b), first);
+		if (_mm256_testz_si256(_mm256_or_si256(da, db), _mm256_set1_epi16(-1))) {
+			_mm256_storeu_si256((__m256i *) (out + i), _mm256_loadu_si256((const __m256i *) (lut + sym[i])));
+			i += 32;
+			continue;
+		}
+		/* the same two shapes on the first 16 symbols alone (a line ends inside the group), else 8 through the table */
+		if (_mm256_testz_si256(a, hi)) {
+			_mm_storeu_si128((__m128i *) (out + i), _mm_packus_epi16(_mm256_castsi256_si128(a), _mm256_extracti128_si256(a, 1)));
+			i += 16;
+			continue;
+		}
+		if (_mm256_testz_si256(da, _mm256_set1_epi16(-1))) {
+			_mm_storeu_si128((__m128i *) (out + i), _mm_loadu_si128((const __m128i *) (lut + sym[i])));
+			i += 16;
+			continue;
+		}
+		table_run(lut, sym + i, 8, out + i);
+		i += 8;
 	}
 	table_run(lut, sym + i, n - i, out + i);
 }
 #endif
 } // namespace
 
-bool SpecInflate::resolve(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out)
+bool SpecInflate::resolve(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out, uint32_t *crc)
 {
-	uint8_t lut[65536];                                         /* on the caller's stack: 0 .. 255 and 32768 .. 65535 are the only entries ever read */
-	for (int i = 0; i < 256; ++i) lut[i] = (uint8_t) i;
+	uint8_t lut[65536 + 32];                                    /* on the caller's stack: 0 .. 255 and 32768 .. 65535 are the only entries ever used */
+	for (int i = 0; i < 256 + 32; ++i) lut[i] = (uint8_t) i;      /* (+ 32: the 32-byte loads of resolve_avx2 stay inside initialised memory) */
 	memcpy(lut + kMarker, window, kWindow);
+	memset(lut + 65536, 0, 32);
 #if defined(__x86_64__)
 	static const bool avx2 = __builtin_cpu_supports("avx2");
-	if (avx2) resolve_avx2(lut, sym, n, out);
-	else
+#else
+	constexpr bool avx2 = false;
 #endif
-		table_run(lut, sym, n, out);
+	/* in pieces that stay in the cache between the two passes when the caller wants the CRC-32 of the bytes as well */
+	const size_t step = crc ? (size_t) 32768 : n;
+	uint32_t c = crc ? *crc : 0;
+	for (size_t at = 0; at < n; at += step) {
+		const size_t m = std::min(step, n - at);
+#if defined(__x86_64__)
+		if (avx2) resolve_avx2(lut, sym + at, m, out + at);
+		else
+#endif
+			table_run(lut, sym + at, m, out + at);
+		if (crc) c = crc32_fast(c, out + at, m);
+	}
+	if (crc) *crc = c;
 	if (valid < kWindow) {                                      /* a marker in front of the member's first byte: invalid distance */
 		const uint16_t lowest = (uint16_t) (kMarker | (kWindow - valid));
 		for (size_t j = 0; j < n; ++j) if (sym[j] >= 256 && sym[j] < lowest) return false;

@@ -41,8 +41,9 @@ public:
 	static void fill_markers(uint16_t *sym);                 /* sym[j] = kMarker | j, j < kWindow */
 	/* bytes of n symbols: literal -> itself, marker -> window[j] (window = the 32768 bytes in front of the chunk; only the
 	 * last `valid` of them exist: a marker below kWindow - valid refers to data before the start of the member).  Returns
-	 * false on such a marker (the chunk is then decoded again in order, which reports the error where zlib does). */
-	static bool resolve(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out);
+	 * false on such a marker (the chunk is then decoded again in order, which reports the error where zlib does).
+	 * crc != nullptr: *crc is continued over the n bytes (crc32_fast.hpp), 32 KiB at a time right behind the bytes' making. */
+	static bool resolve(const uint16_t *sym, size_t n, const uint8_t *window, size_t valid, uint8_t *out, uint32_t *crc = nullptr);
 
 private:
 	NTSM_INFLATE_CLONES Status run_huffman16(uint16_t *buf, size_t *out, size_t out_stop);
