@@ -278,7 +278,12 @@ NTSM_INFLATE_CLONES Inflate::Status Inflate::run_huffman(uint8_t *buf, size_t *o
 			const uint8_t *src = op - dist;
 			uint8_t *const end = op + len;
 			if (dist >= 8) {
-				do { store64(op, load64(src)); op += 8; src += 8; } while (op < end);
+				store64(op, load64(src));                             /* 16 bytes unconditionally: text is mostly matches of 6-9, a branch at 8 would be a coin toss */
+				store64(op + 8, load64(src + 8));
+				if (len > 16) {
+					op += 16; src += 16;
+					do { store64(op, load64(src)); op += 8; src += 8; } while (op < end);
+				}
 			} else if (dist == 1) {
 				const uint64_t v = 0x0101010101010101ull * *src;
 				do { store64(op, v); op += 8; } while (op < end);

@@ -146,10 +146,11 @@ NTSM_INFLATE_CLONES Inflate::Status SpecInflate::run_huffman16(uint16_t *buf, si
 			const uint16_t *src = op - dist;
 			uint16_t *const end = op + len;
 			if (dist >= 8) {
-				/* 8 symbols at a time; DNA text is mostly matches of 6-9 symbols, which this takes without a loop */
+				/* 8 symbols at a time; DNA text is mostly matches of 6-9 symbols, which the first two take without a loop */
 				copy16(op, src);
-				if (len > 8) {
-					op += 8; src += 8;
+				copy16(op + 8, src + 8);                              /* unconditionally: one well-predicted branch for len > 16 instead of a coin toss at 8 */
+				if (len > 16) {
+					op += 16; src += 16;
 					do { copy16(op, src); op += 8; src += 8; } while (op < end);
 				}
 			} else if (dist >= 4) {
