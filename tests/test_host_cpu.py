@@ -884,6 +884,18 @@ def test_parallel_site_loading_equals_sequential(nt, tmp_path):
         f.write(raw)
     a, b = nt.Sites(sp), nt.Sites(gz)
     assert np.array_equal(a.keys, b.keys) and a.n_sites == b.n_sites
+    # the grouping of equal k-mers and the allele lists are built on several threads at this size: against the oracle's
+    # loader (one hash table, stream order) on the file with the repeated records, and what both print for the same reads
+    for name, dupes in (("plain.fa", False), ("dups.fa", True)):
+        p = str(tmp_path / name)
+        sites, fp = nt.Sites(p, allow_dupes=dupes), OracleFP(p, k=19, dupes=dupes)
+        assert sites.n_sites == fp.n_sites and len(sites.keys) == fp.n_distinct
+        for i in range(0, 3000, 7):
+            fp.process(raw.split(b"\n", 2 * i + 2)[1 + 2 * i].replace(b"N", b"A"))
+        canon, _, cnt = fp.kmers()
+        assert np.array_equal(sites.keys, canon)
+        rc, text = sites.format_counts(cnt, fp.total_kmers)
+        assert (rc, text) == fp.print_counts()
 
 
 def test_reader_on_a_fifo(nt, tmp_path):
