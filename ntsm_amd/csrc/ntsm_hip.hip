@@ -911,6 +911,7 @@ struct Slot {
 	uint8_t *d_packed = nullptr;               /* packed lanes: device copy of codes + validity bits (3/8 byte per position) */
 	uint64_t *h_read_end = nullptr, *d_read_end = nullptr;
 	uint64_t h_bases_bytes = 0, h_ends_bytes = 0;
+	uint64_t d_bases_bytes = 0, d_packed_bytes = 0;   /* sizes of the device buffers (device_cache of the context) */
 	bool ends_on_device = true;                /* false (lanes): read_end never leaves the host, plain malloc */
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;                 /* last use of the host buffer finished */
@@ -1019,8 +1020,13 @@ struct ntsm_ctx {
 	uint64_t t_launches = 0;
 	double t_ms = 0;
 	/* producer lanes (ntsm_lane_*): several host threads feeding this context */
-	std::mutex mu;                             /* guards open_lanes, lane_stream, the lane totals fold-in and the timing pool */
+	std::mutex mu;                             /* guards open_lanes, lane_stream, the lane totals fold-in, the timing pool and device_cache */
 	int open_lanes = 0;
+	/* Device buffers of closed lanes, kept for the next lane of the same size (and for the process's end): hipFree waits for
+	 * the device and costs 0.2 ms a call, 12 ms for the sixteen lanes of an `ntsmCount -t 16` run that is otherwise over.
+	 * At most kDeviceCacheMax entries; the oldest is freed when one more comes in.  Released by ntsm_destroy. */
+	std::vector<std::pair<void *, uint64_t>> device_cache;
+	static constexpr size_t kDeviceCacheMax = 128;
 	hipStream_t lane_stream[2] = { nullptr, nullptr };   /* shared by all lanes (round robin): a stream costs 14 ms to create */
 	unsigned lanes_opened = 0;
 };
@@ -1062,26 +1068,44 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 			std::vector<uint32_t> owner(slots, 0);            /* dense index stored in each slot */
 			bool ok = true;
 			uint64_t rng = 0x9E3779B97F4A7C15ull;
+			/* 1.5 M keys go into 64 MB of slots at random: every insertion is two cache misses unless its two buckets are asked
+			 * for a few dozen keys ahead (0.055 s -> 0.015 s for the human set) */
+			constexpr uint32_t kAhead = 24;
+			auto buckets_of = [&](uint64_t key, uint64_t b[2]) {
+				const uint32_t f = ntsm_fold(key);
+				b[0] = 2ull * (ntsm_h1(f) >> bshift);
+				b[1] = 2ull * (ntsm_h2(f) >> bshift);
+			};
+			for (uint32_t i = 0; i < n && i < kAhead; ++i) {
+				uint64_t b[2];
+				buckets_of(c->canon[i], b);
+				__builtin_prefetch(&keys[b[0]], 1);
+				__builtin_prefetch(&keys[b[1]], 1);
+			}
 			for (uint32_t i = 0; i < n && ok; ++i) {
+				if (i + kAhead < n) {
+					uint64_t b[2];
+					buckets_of(c->canon[i + kAhead], b);
+					__builtin_prefetch(&keys[b[0]], 1);
+					__builtin_prefetch(&keys[b[1]], 1);
+				}
 				uint64_t key = c->canon[i];
 				uint32_t idx = i;
+				uint64_t b[2];
+				buckets_of(key, b);
 				/* duplicate check against both candidate buckets */
-				{
-					const uint32_t f = ntsm_fold(key);
-					const uint64_t b[2] = { 2ull * (ntsm_h1(f) >> bshift), 2ull * (ntsm_h2(f) >> bshift) };
-					for (int q = 0; q < 2; ++q)
-						for (int s = 0; s < 2; ++s)
-							if (keys[b[q] + s] == key) { cuckoo_rc = NTSM_ERR_DUP_KEY; return; }
-				}
+				for (int q = 0; q < 2; ++q)
+					for (int s = 0; s < 2; ++s)
+						if (keys[b[q] + s] == key) { cuckoo_rc = NTSM_ERR_DUP_KEY; return; }
 				bool placed = false;
 				for (int kick = 0; kick < 1000 && !placed; ++kick) {
-					const uint32_t f = ntsm_fold(key);
-					const uint64_t b[2] = { 2ull * (ntsm_h1(f) >> bshift), 2ull * (ntsm_h2(f) >> bshift) };
+					if (kick) buckets_of(key, b);
 					for (int q = 0; q < 2 && !placed; ++q)
 						for (int s = 0; s < 2 && !placed; ++s)
 							if (keys[b[q] + s] == NTSM_EMPTY_KEY) {
 								keys[b[q] + s] = key;
 								owner[b[q] + s] = idx;
+								c->slot_of[idx] = (uint32_t) (b[q] + s);
 								placed = true;
 							}
 					if (placed) break;
@@ -1089,12 +1113,11 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 					const uint64_t victim = b[(rng >> 33) & 1] + ((rng >> 34) & 1);
 					std::swap(key, keys[victim]);
 					std::swap(idx, owner[victim]);
+					c->slot_of[owner[victim]] = (uint32_t) victim;   /* the key that moved in; the one that moved out is placed next */
 				}
 				if (!placed) ok = false;
 			}
 			if (!ok) continue;                                /* grow and retry */
-			for (uint64_t s = 0; s < slots; ++s)
-				if (keys[s] != NTSM_EMPTY_KEY) c->slot_of[owner[s]] = (uint32_t) s;
 			c->n_slots = slots;
 			c->bucket_log2 = blog;
 			break;
@@ -1162,7 +1185,10 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 			blocks.assign(c->n_blocks * 4, 0u);
 			std::vector<uint32_t> site_mz;                            /* two-level path: every site k-mer's minimizer */
 			if (c->two_level) site_mz.resize(n);
-			for (uint32_t i = 0; i < n; ++i) {
+			/* the minimizer of a key is eight hashes and a reverse complement (40 ns): with the table build down to 15 ms this
+			 * loop is what the four structures wait for, so it is cut into ranges of keys; the bits are OR-ed atomically */
+			auto fill_blocks = [&](uint32_t lo, uint32_t hi) {
+			for (uint32_t i = lo; i < hi; ++i) {
 				const uint64_t x = c->canon[i];
 				/* reverse complement of the 2k-bit code: complement, then reverse the 2-bit groups of the 64-bit word */
 				uint64_t rc = ~x;
@@ -1179,10 +1205,18 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 				if (c->two_level) site_mz[i] = mz;
 				const uint32_t u = ntsm_kmer_sum(ntsm_code_top(x, plan.k), ntsm_code_top(rc, plan.k)), um = ntsm_kmer_mix(u);
 				uint32_t *blk = &blocks[(size_t) ntsm_block_idx(mz, c->blk_map) * 4];
-				blk[0] |= 1u << NTSM_KBIT0(u);
-				blk[1] |= 1u << NTSM_KBIT1(um);
-				blk[2] |= 1u << NTSM_KBIT2(um);
-				blk[3] |= 1u << NTSM_KBIT3(um);
+				__atomic_fetch_or(&blk[0], 1u << NTSM_KBIT0(u), __ATOMIC_RELAXED);
+				__atomic_fetch_or(&blk[1], 1u << NTSM_KBIT1(um), __ATOMIC_RELAXED);
+				__atomic_fetch_or(&blk[2], 1u << NTSM_KBIT2(um), __ATOMIC_RELAXED);
+				__atomic_fetch_or(&blk[3], 1u << NTSM_KBIT3(um), __ATOMIC_RELAXED);
+			}
+			};
+			{
+				const uint32_t parts = n >= (1u << 18) ? 4u : 1u;
+				std::vector<std::thread> pool;
+				for (uint32_t t = 1; t < parts; ++t) pool.emplace_back(fill_blocks, (uint32_t) ((uint64_t) n * t / parts), (uint32_t) ((uint64_t) n * (t + 1) / parts));
+				fill_blocks(0, (uint32_t) ((uint64_t) n / parts));
+				for (auto &th : pool) th.join();
 			}
 			if (c->two_level) {
 				/* Bloom over the DISTINCT site minimizers: one 32-bit word per minimizer, two bits; 12 bits per distinct
@@ -1352,7 +1386,36 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 	return NTSM_OK;
 }
 
-int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device, bool packed_only = false)
+/* device memory of a lane slot: from the context's cache of closed lanes' buffers when one of that size is there */
+hipError_t device_take(ntsm_ctx *c, void **p, uint64_t bytes)
+{
+	if (c) {
+		std::lock_guard<std::mutex> lk(c->mu);
+		for (size_t i = c->device_cache.size(); i-- > 0;)
+			if (c->device_cache[i].second == bytes) {
+				*p = c->device_cache[i].first;
+				c->device_cache.erase(c->device_cache.begin() + (long) i);
+				return hipSuccess;
+			}
+	}
+	return hipMalloc(p, bytes);
+}
+
+void device_give(ntsm_ctx *c, void *p, uint64_t bytes)
+{
+	if (!p) return;
+	void *evict = nullptr;
+	if (c && bytes) {
+		std::lock_guard<std::mutex> lk(c->mu);
+		if (c->device_cache.size() >= ntsm_ctx::kDeviceCacheMax) { evict = c->device_cache.front().first; c->device_cache.erase(c->device_cache.begin()); }
+		c->device_cache.emplace_back(p, bytes);
+		p = nullptr;
+	}
+	if (evict) (void) hipFree(evict);
+	if (p) (void) hipFree(p);
+}
+
+int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device, bool packed_only = false, ntsm_ctx *cache = nullptr)
 {
 	s.ends_on_device = ends_on_device;
 	s.h_bases_bytes = (packed_only ? (cap_bytes & ~31ull) / 4 + (cap_bytes & ~31ull) / 8 : cap_bytes) + 64;   /* packed: 3/8 byte per position */
@@ -1367,7 +1430,8 @@ int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool
 		s.h_read_end = (uint64_t *) malloc(s.h_ends_bytes);
 		if (!s.h_read_end) return NTSM_ERR_NOMEM;
 	}
-	HIPCHK(hipMalloc(&s.d_bases, cap_bytes + 64));
+	s.d_bases_bytes = cap_bytes + 64;
+	HIPCHK(device_take(cache, (void **) &s.d_bases, s.d_bases_bytes));
 	if (!s.stream) {
 		s.stream = stream_get(device);
 		if (!s.stream) return NTSM_ERR_HIP;
@@ -1378,15 +1442,15 @@ int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool
 	return NTSM_OK;
 }
 
-void free_slot(Slot &s)
+void free_slot(Slot &s, ntsm_ctx *cache = nullptr)
 {
 	if (s.h_bases && !pool_free(s.h_bases, s.h_bases_bytes)) (void) hipHostFree(s.h_bases);
 	if (s.h_read_end) {
 		if (!s.ends_on_device) free(s.h_read_end);
 		else if (!pool_free(s.h_read_end, s.h_ends_bytes)) (void) hipHostFree(s.h_read_end);
 	}
-	if (s.d_bases) (void) hipFree(s.d_bases);
-	if (s.d_packed) (void) hipFree(s.d_packed);
+	device_give(cache, s.d_bases, s.d_bases_bytes);
+	device_give(cache, s.d_packed, s.d_packed_bytes);
 	if (s.d_read_end) (void) hipFree(s.d_read_end);
 	s.h_bases = s.d_bases = s.d_packed = nullptr;
 	s.h_read_end = s.d_read_end = nullptr;
@@ -1911,6 +1975,8 @@ void ntsm_destroy(ntsm_ctx *c)
 	if (c->d_tab) (void) hipFree(c->d_tab);
 	if (c->d_tblocks) (void) hipFree(c->d_tblocks);
 #endif
+	for (auto &b : c->device_cache) (void) hipFree(b.first);
+	c->device_cache.clear();
 	void *ptrs[] = { c->d_bloom, c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
 	for (void *p : ptrs) if (p) (void) hipFree(p);
 	delete c;
@@ -2041,10 +2107,10 @@ static int lane_open(ntsm_ctx *c, uint64_t cap_bytes, uint64_t cap_reads, bool p
 	for (int i = 0; i < 2; ++i) {
 		Slot &s = l->slot[i];
 		s.stream = st;
-		int rc = alloc_slot(s, c->device, cap_bytes, cap_reads, false, packed_only);
+		int rc = alloc_slot(s, c->device, cap_bytes, cap_reads, false, packed_only, c);
 		if (rc) {
 			for (auto &q : l->slot) {
-				free_slot(q);
+				free_slot(q, c);
 				if (q.done) (void) hipEventDestroy(q.done);
 			}
 			delete l;
@@ -2108,7 +2174,10 @@ int ntsm_lane_acquire_packed(ntsm_lane *l, uint8_t **codes, uint8_t **valid, uin
 	if (rc) return rc;
 	/* the slot's pinned buffer (cap_bytes + 64) holds both planes of up to cap_bytes positions: 3/8 of it */
 	const uint64_t cap_pos = l->cap_bytes & ~31ull;
-	if (!s.d_packed) HIPCHK(hipMalloc(&s.d_packed, cap_pos / 4 + cap_pos / 8 + 64));
+	if (!s.d_packed) {
+		s.d_packed_bytes = cap_pos / 4 + cap_pos / 8 + 64;
+		HIPCHK(device_take(l->c, (void **) &s.d_packed, s.d_packed_bytes));
+	}
 	s.acquired = true;
 	*codes = s.h_bases;
 	*valid = s.h_bases + cap_pos / 4;
@@ -2157,7 +2226,7 @@ int ntsm_lane_close(ntsm_lane *l)
 	for (auto &s : l->slot) {                            /* the stream is shared: wait for this lane's own batches only */
 		if (s.busy && hipEventSynchronize(s.done) != hipSuccess) rc = NTSM_ERR_HIP;
 		s.busy = false;
-		free_slot(s);
+		free_slot(s, c);                                  /* device buffers go to the context's cache (nothing of this lane is in flight any more) */
 		if (s.done) (void) hipEventDestroy(s.done);
 	}
 	{
