@@ -1278,6 +1278,39 @@ def test_cli_clean_exit_runs_the_destructors(nt):
         assert a.stdout == b.stdout and len(a.stdout) > 1000 and _summary(a.stderr) == _summary(b.stderr)
 
 
+def test_cli_hands_its_teardown_to_a_child(nt, tmp_path):
+    """After the last line is printed the CLI starts a clone(CLONE_VM) child that outlives it by the kernel's teardown of
+    the HIP process (ntsm_count_main.cpp: hand_over_teardown) and leaves.  Same bytes and exit status as with the teardown
+    inside exit(2) (NTSM_SYNC_EXIT=1); the child closes its copies of stdout / stderr at once (a reader of the pipes sees the
+    end when the CLI goes, not 0.15 s later) and is gone -- at most a zombie waiting for init -- a moment afterwards; a run
+    that fails (no such input) takes the ordinary exit and leaves nothing behind either."""
+    import time
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    inp = os.path.join(G, "inputs")
+    args = ["-s", "sites200.fa", "-t", "4", "reads2k.fq", "reads600.fq.gz"]
+    a = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, NTSM_SYNC_EXIT="1"))
+    assert a.returncode == 0 and len(a.stdout) > 1000
+    def live_ntsm():
+        out = subprocess.run(["ps", "-eo", "pid,stat,comm"], stdout=subprocess.PIPE).stdout.decode().split("\n")
+        return [l for l in out if "ntsmCount" in l and " Z" not in l]
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        b = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        walls.append(time.perf_counter() - t0)
+        assert b.returncode == 0 and b.stdout == a.stdout and _summary(b.stderr) == _summary(a.stderr)
+        own = [l for l in b.stderr.decode().split("\n") if l.startswith("Time: ")]
+        # everything after `Time:` -- the pipes' end included -- comes within a few hundredths of a second
+        assert walls[-1] - float(own[-1].split()[1]) < 0.1, (walls[-1], own)
+    deadline = time.time() + 5
+    while live_ntsm() and time.time() < deadline:
+        time.sleep(0.05)
+    assert not live_ntsm()
+    subprocess.run([exe, "-s", "no_such_sites.fa", "reads2k.fq"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    time.sleep(0.3)
+    assert not live_ntsm()
+
+
 def test_cli_reads_from_pipes(nt):
     """`ntsmCount -s sites.fa <(zcat a.fq.gz) <(cat b.fq)`: inputs that are pipes (process substitution) give the bytes
     of the same run on the files, with -t 1 and -t 2."""

@@ -94,6 +94,8 @@ while time.time() < t_end:
                NTSM_GZ_DECODERS=str(rng.choice([0, 2, 5])), NTSM_EARLY=rng.choice(["gz", "plain", "all"]))
     if rng.random() < 0.3:
         env["NTSM_NO_EARLY"] = "1"
+    if rng.random() < 0.3:
+        env["NTSM_SYNC_EXIT"] = "1"                            # teardown inside exit(2) instead of the CLONE_VM child
     ref = subprocess.run([ORA] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     got = subprocess.run([EXE] + args + ["-t", str(t)] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     ok = (ref.returncode == got.returncode or (ref.returncode == 134 and got.returncode == -6)) and ref.stdout == got.stdout
