@@ -308,6 +308,19 @@ def test_block_parallel_ingest_under_tsan(nt, tmp_path):
             assert p.returncode == 0, p.stderr.decode()[-3000:]
             outs.add(p.stdout.split(b" parallel=")[0] + b" " + p.stdout.split(b" ")[-1])
         assert len(outs) == 1, outs
+    # the site loader's own threads (k-merising, hash-bucketed sorts, allele lists) on a file big enough for all of them,
+    # with repeated records (duplicate k-mers, collision warnings): same keys as the sequential first pass
+    sp = str(tmp_path / "sites.fa")
+    nt.SynthShort(sites_seed=3, n_sites=8000, read_seed=1, sites_path=sp)
+    raw = open(sp, "rb").read()
+    open(sp, "wb").write(raw + b"\n".join(raw.split(b"\n")[:400]) + b"\n")
+    outs = set()
+    for extra in ({}, {"NTSM_SITES_SEQUENTIAL": "1"}):
+        for dupes in ("0", "1"):
+            p = subprocess.run([exe, sp, "sites", "19", dupes], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, **extra))
+            assert p.returncode == 0 and b"ThreadSanitizer" not in p.stderr, p.stderr.decode()[-3000:]
+            outs.add((dupes, p.stdout))
+    assert len(outs) == 2, outs
 
 
 def _gz_member(data, level=6, strategy=0, wbits=15, memlevel=8):

@@ -1,9 +1,12 @@
 /* Driver for running the block-parallel FASTQ ingest under ThreadSanitizer (tests/test_host_cpu.py):
  *   parallel_tsan FILE THREADS BLOCK_BYTES        ->  "reads=N bytes=M parallel=P resume=R fnv=..."
  *   parallel_tsan FILE.gz DECODERS PARSERS SINK CHUNK  (five arguments: the parallel gzip ingest, parallel_gz_fastq.hpp)
- *                                                  ->  "reads=N bytes=M parallel=P pieces=Q status=S sum=..." (sum: order-free) */
+ *                                                  ->  "reads=N bytes=M parallel=P pieces=Q status=S sum=..." (sum: order-free)
+ *   parallel_tsan SITES.fa sites K                 (the site loader's threads: k-merising, bucketed sorts, allele lists)
+ *                                                  ->  "keys=N sites=S erased=E fnv=..." */
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "../include/ntsm_host.h"
 
@@ -12,6 +15,18 @@ int main(int argc, char **argv)
 	if (argc < 4) return 2;
 	uint8_t *bases = nullptr;
 	uint64_t *ends = nullptr, nb = 0, nr = 0, nblk = 0, npar = 0, resume = 0;
+	if (!strcmp(argv[2], "sites")) {
+		ntsm_sites *st = nullptr;
+		int rc = ntsm_sites_load(argv[1], (unsigned) atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 0, &st);
+		if (rc) { fprintf(stderr, "rc=%d\n", rc); return 1; }
+		uint64_t h = 1469598103934665603ull;
+		const uint64_t *keys = ntsm_sites_keys(st);
+		for (uint64_t i = 0; i < ntsm_sites_n_keys(st); ++i) h = (h ^ keys[i]) * 1099511628211ull;
+		printf("keys=%llu sites=%llu erased=%llu fnv=%016llx\n", (unsigned long long) ntsm_sites_n_keys(st), (unsigned long long) ntsm_sites_n_sites(st),
+				(unsigned long long) ntsm_sites_n_erased(st), (unsigned long long) h);
+		ntsm_sites_free(st);
+		return 0;
+	}
 	if (argc >= 8) {   /* parallel_tsan FILE early PARSERS DECODERS BLOCK CHUNK_POSITIONS BUDGET CONSUMERS: early_ingest.hpp */
 		uint8_t *text = nullptr;
 		uint64_t nt = 0, nreads = 0, nbases = 0, npar2 = 0;
