@@ -252,6 +252,17 @@ void Feeder::feedRead(const char *seq, uint64_t len)
 	m_fill += 1;
 }
 
+namespace {
+/* a regular file of at least min_bytes that starts with the gzip magic: gets the decoder pool (plain or BGZF) */
+bool big_gzip_input(const std::string &fn, uint64_t min_bytes)
+{
+	struct stat st;
+	return stat(fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (uint64_t) st.st_size >= min_bytes && GzStream::is_gzip(fn);
+}
+/* from this many big .gz inputs on they are read side by side, one reader per file, instead of one after the other with the whole pool */
+size_t side_by_side_from(unsigned threads) { return std::max<size_t>(3, threads / 4); }
+} // namespace
+
 FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 {
 	if (m_opt.devices.empty()) m_opt.devices.push_back(m_opt.device);
@@ -281,7 +292,12 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 	/* the first input file starts being parsed now, into ordinary memory (early_ingest.hpp): -t N, no -m, no -vvv */
 	{
 		const bool maybe_armed = m_opt.covThresh != 0 && m_opt.covThresh < 1e300;
-		if (m_opt.early && m_opt.pack && m_opt.threads > 1 && !maybe_armed && m_opt.verbose <= 2 && !m_opt.inputs.empty()) {
+		/* several big .gz inputs are read side by side (computeCounts), the first one included: measured with 8 / 4 files of
+		 * 4e7 reads in total, -t 16: 0.97 / 1.03 s against 1.07 / 1.35 s with the first file taken early and alone */
+		size_t n_big_gz = 0;
+		for (const std::string &fn : m_opt.inputs) n_big_gz += big_gzip_input(fn, m_opt.gz_parallel_min_bytes) ? 1 : 0;
+		const bool side_by_side = !getenv("NTSM_ZLIB_ONLY") && n_big_gz >= side_by_side_from(m_opt.threads);
+		if (m_opt.early && !side_by_side && m_opt.pack && m_opt.threads > 1 && !maybe_armed && m_opt.verbose <= 2 && !m_opt.inputs.empty()) {
 			const unsigned n_par = std::min(m_opt.threads, 16u);
 			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
 			const unsigned n_dec = m_opt.gz_decoders ? m_opt.gz_decoders : std::min(std::min(12u, hw), 2 * m_opt.threads);   /* fewer than later: the start-up has threads of its own */
@@ -337,6 +353,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 FingerPrint::~FingerPrint()
 {
 	joinPrep();
+	for (auto &t : m_retire) if (t.joinable()) t.join();
 	m_main.reset();
 	m_lanes.clear();
 	for (ntsm_ctx *c : m_ctx) ntsm_destroy(c);
@@ -395,7 +412,7 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 		drainEarly();                                            /* the first file has been in the works since the process started */
 		todo.erase(todo.begin());
 	}
-	m_early.reset();
+	retireLater(std::move(m_early));
 	const std::vector<std::string> &files_left = todo;
 	/* Big plain FASTQ files are cut into blocks and parsed by all threads (parallel_fastq.hpp); files that are not
 	 * eligible (gzip, FASTA, wrapped or CR lines, small) are taken whole, one thread per file. */
@@ -434,9 +451,16 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 	 * parallel by the same feeders (parallel_gz_fastq.hpp); small ones and NTSM_ZLIB_ONLY stay one thread per file. */
 	if (!getenv("NTSM_ZLIB_ONLY")) {
 		std::vector<std::string> small;
+		auto is_big_gz = [&](const std::string &fn) { return big_gzip_input(fn, m_opt.gz_parallel_min_bytes); };
+		/* Many big files (a lane's worth of .fq.gz: four or more left with -t 16) are better off side by side, one reader per file
+		 * with the -t threads' worth of decoders shared out among them (the route below), than one after the other with the
+		 * whole pool each: every file pays the pool's start and its drain, and the in-order share of the decoding is the
+		 * cheapest (no block search, no marker pass).  Measured, 8 x 262 MB of .gz, -t 16: 1.49 s one after the other. */
+		size_t n_big = 0;
+		for (const std::string &fn : rest) n_big += is_big_gz(fn) ? 1 : 0;
+		const bool side_by_side = n_big >= side_by_side_from((unsigned) want);
 		for (const std::string &fn : rest) {
-			struct stat st;
-			if (!(stat(fn.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (uint64_t) st.st_size >= m_opt.gz_parallel_min_bytes && GzStream::is_gzip(fn))) { small.push_back(fn); continue; }
+			if (side_by_side || !is_big_gz(fn)) { small.push_back(fn); continue; }
 			const auto tp0 = std::chrono::steady_clock::now();
 			const size_t n_par = std::min<size_t>(want, 16);
 			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
@@ -472,6 +496,7 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 				          << ps[0] << " chunks spliced, " << ps[1] << " dropped), rest "
 				          << std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count() << " s" << std::endl;
 			}
+			retireLater(std::move(gz));                             /* null if the sequential reader took it over (and closed it) */
 		}
 		rest.swap(small);
 		GzStream::set_decoder_threads((unsigned) std::max<size_t>(1, m_opt.threads / std::max<size_t>(1, std::min(want, std::max<size_t>(1, rest.size())))));

@@ -132,6 +132,14 @@ private:
 	std::unique_ptr<Feeder> m_main;                      /* context [0]'s own staging: single-threaded and -m runs */
 	std::vector<std::unique_ptr<Feeder>> m_lanes;        /* -t N: one producer lane per host thread */
 	std::unique_ptr<class EarlyIngest> m_early;          /* the first input file, parsed while the sites load (early_ingest.hpp) */
+	/* A finished gzip stream holds 0.5-0.8 GB of buffers it touched (symbol buffers of the decoder pool, pieces): giving them
+	 * back costs the kernel 0.07-0.1 s per stream, which used to sit between two files and in front of the last line.  Streams
+	 * are therefore destroyed on a side thread while the next file is read (joined by the destructor; _exit does not wait). */
+	std::vector<std::thread> m_retire;
+	template <class T> void retireLater(std::unique_ptr<T> p)
+	{
+		if (p) m_retire.emplace_back([q = std::shared_ptr<T>(std::move(p))]() mutable { q.reset(); });
+	}
 	void drainEarly();                                   /* its chunks -> the lanes */
 	/* results */
 	bool m_fetched = false;
