@@ -447,8 +447,9 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
         os.unlink(gz)
         assert hashlib.sha256(pz.stdout).hexdigest() == sha_cli, "counts.txt of the .gz run differs from the plain FASTQ's"
         infl = None
+        early = any("early ingest" in l for l in phases)      # then the inflate started with the process and that line covers only the stream's rest
         for l in phases:
-            if "inflate+parse+count" in l:
+            if "inflate+parse+count" in l and not early:
                 try:
                     infl = float(l.split("inflate+parse+count")[1].split("s")[0])
                 except ValueError:

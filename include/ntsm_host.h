@@ -64,6 +64,12 @@ int ntsm_host_flatten_parallel_gz(const char *path, unsigned n_decoders, unsigne
  * letters are the maximal runs of valid bases of the reads.  Returns 0, 1 if the file is not taken by this path. */
 int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions, uint64_t max_chunks,
 		unsigned n_consumers, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases, uint64_t *n_parallel);
+/* The same with the hand-over of a gzip stream (EarlyIngest::hand_over / release_stream): once `hand_over_after` chunks have
+ * been drained the consumers ask for the stream; what it still holds is read by the sequential reader and appended to *text in
+ * the same alphabet.  *n_rest = reads that came that way (0: the whole file went through the chunks, or a plain file). */
+int ntsm_host_early_ingest_hand_over(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions,
+		uint64_t max_chunks, unsigned n_consumers, uint64_t hand_over_after, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases,
+		uint64_t *n_parallel, uint64_t *n_rest);
 void ntsm_host_gunzip_parallel_chunk(uint64_t bytes);
 void ntsm_host_gunzip_parallel_stats(uint64_t stats[2]);
 /* Block-parallel variant for plain 4-line FASTQ (ntsm_amd/csrc/host/parallel_fastq.hpp), for tests: the records

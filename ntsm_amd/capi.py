@@ -103,6 +103,7 @@ _sig(HO, "ntsm_host_free", None, [C.c_void_p])
 _sig(HO, "ntsm_host_gunzip", C.c_int, [C.c_char_p, C.c_int, C.c_uint, C.POINTER(u8p), u64p])
 _sig(HO, "ntsm_host_flatten_parallel_gz", C.c_int, [C.c_char_p, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, C.POINTER(C.c_int)])
 _sig(HO, "ntsm_host_early_ingest", C.c_int, [C.c_char_p, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.POINTER(u8p), u64p, u64p, u64p, u64p])
+_sig(HO, "ntsm_host_early_ingest_hand_over", C.c_int, [C.c_char_p, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, u64p, u64p, u64p, u64p])
 _sig(HO, "ntsm_host_gunzip_parallel_chunk", None, [C.c_uint64])
 _sig(HO, "ntsm_host_gunzip_parallel_stats", None, [u64p])
 _sig(HO, "ntsm_host_flatten_parallel", C.c_int, [C.c_char_p, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, u64p])
@@ -262,20 +263,28 @@ def flatten_file_parallel_gz(path, n_decoders=4, n_parsers=4, sink_bytes=1 << 20
     return bases, ends, dict(pieces=int(npc.value), parallel_records=int(npar.value), status=int(st.value))
 
 
-def early_ingest(path, n_parsers=4, n_decoders=4, block_bytes=1 << 20, chunk_positions=1 << 20, max_chunks=64, n_consumers=2):
+def early_ingest(path, n_parsers=4, n_decoders=4, block_bytes=1 << 20, chunk_positions=1 << 20, max_chunks=64, n_consumers=2, hand_over_after=None):
     """Early ingest (early_ingest.hpp) of one file into packed chunks; None when the file is not taken by that path.
-    Returns (text bytes: A C G T for valid positions, N otherwise; n_reads; n_bases; parallel_records)."""
+    Returns (text bytes: A C G T for valid positions, N otherwise; n_reads; n_bases; parallel_records) -- and, with
+    hand_over_after = n (the consumers ask for a gzip stream once n chunks are drained; its rest is read sequentially), a fifth
+    element: the reads that did not go through the chunks."""
     t = u8p()
-    nt_, nr, nb, npar = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
-    rc = HO.ntsm_host_early_ingest(os.fsencode(path), n_parsers, n_decoders, block_bytes, chunk_positions, max_chunks, n_consumers,
-                                   C.byref(t), C.byref(nt_), C.byref(nr), C.byref(nb), C.byref(npar))
+    nt_, nr, nb, npar, nrest = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    if hand_over_after is None:
+        rc = HO.ntsm_host_early_ingest(os.fsencode(path), n_parsers, n_decoders, block_bytes, chunk_positions, max_chunks, n_consumers,
+                                       C.byref(t), C.byref(nt_), C.byref(nr), C.byref(nb), C.byref(npar))
+    else:
+        rc = HO.ntsm_host_early_ingest_hand_over(os.fsencode(path), n_parsers, n_decoders, block_bytes, chunk_positions, max_chunks, n_consumers, hand_over_after,
+                                                 C.byref(t), C.byref(nt_), C.byref(nr), C.byref(nb), C.byref(npar), C.byref(nrest))
     if rc == 1:
         return None
     if rc:
         raise NtsmError("early_ingest(%s) failed: %d" % (path, rc))
     text = C.string_at(t, nt_.value)
     HO.ntsm_host_free(t)
-    return text, int(nr.value), int(nb.value), int(npar.value)
+    if hand_over_after is None:
+        return text, int(nr.value), int(nb.value), int(npar.value)
+    return text, int(nr.value), int(nb.value), int(npar.value), int(nrest.value)
 
 
 def flatten_reads(reads):

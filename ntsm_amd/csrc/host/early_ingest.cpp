@@ -134,6 +134,13 @@ EarlyIngest::EarlyIngest(std::string path, unsigned n_parsers, unsigned n_decode
 	m_thread = std::thread([this]() { run(); });
 }
 
+std::unique_ptr<GzStream> EarlyIngest::release_stream()
+{
+	std::unique_lock<std::mutex> lk(m_mu);
+	m_cv.wait(lk, [&]() { return m_done; });
+	return std::move(m_rest);
+}
+
 EarlyIngest::~EarlyIngest()
 {
 	{
@@ -169,10 +176,12 @@ void EarlyIngest::run()
 		}
 		m_plain.reset();
 	} else {
-		ParallelGzFastq pg(m_gz.get());
+		ParallelGzFastq pg(m_gz.get(), &m_handOver);
 		const ParallelGzFastq::Result r = pg.run(ptrs);
 		m_parallelRecords = r.records;
-		if (!r.complete) {
+		if (r.stopped) {
+			m_rest = std::move(m_gz);                            /* the consumers take it from here (release_stream) */
+		} else if (!r.complete) {
 			SeqReader rd;
 			if (rd.open_stream(std::move(m_gz))) sequential(rd);
 		}

@@ -15,6 +15,7 @@
  */
 #ifndef NTSM_EARLY_INGEST_HPP
 #define NTSM_EARLY_INGEST_HPP
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -57,6 +58,12 @@ public:
 	/* next finished chunk; false once the file has been consumed entirely and every chunk has been handed out */
 	bool next(std::unique_ptr<PackedChunk> *out);
 	void recycle(std::unique_ptr<PackedChunk> c);      /* hand a drained chunk back (its memory is reused) */
+	/* gzip input: the consumers are there now.  No further piece of the stream is parsed into chunks; what is in hand is
+	 * finished (next() still delivers it) and the stream, positioned at a record boundary, can be collected with
+	 * release_stream() once next() has returned false -- its rest is better parsed straight into the lanes (one copy and
+	 * gigabytes of first-touched memory less).  No effect on a plain file. */
+	void hand_over() { m_handOver.store(true); }
+	std::unique_ptr<GzStream> release_stream();        /* null: the whole file went through the chunks */
 	/* statistics for the phase line, valid after next() returned false */
 	uint64_t records() const { return m_records; }
 	uint64_t parallel_records() const { return m_parallelRecords; }
@@ -97,6 +104,8 @@ private:
 	std::deque<std::unique_ptr<PackedChunk>> m_ready, m_free;
 	size_t m_out = 0;                                  /* chunks that exist outside m_free */
 	bool m_done = false, m_abandon = false;
+	std::atomic<bool> m_handOver { false };
+	std::unique_ptr<GzStream> m_rest;                  /* set by run() when the parallel phase ended on hand_over() */
 	uint64_t m_records = 0, m_parallelRecords = 0;
 	std::string m_how;
 	double m_parseSeconds = 0;

@@ -140,7 +140,8 @@ private:
 	{
 		if (p) m_retire.emplace_back([q = std::shared_ptr<T>(std::move(p))]() mutable { q.reset(); });
 	}
-	void drainEarly();                                   /* its chunks -> the lanes */
+	void drainEarly();
+	void countGzStream(std::unique_ptr<class GzStream> gz, const std::string &fn, size_t first_feeder, size_t n_feeders);                                   /* its chunks -> the lanes */
 	/* results */
 	bool m_fetched = false;
 	ntsm_totals m_totals {};

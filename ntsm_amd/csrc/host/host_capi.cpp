@@ -240,14 +240,17 @@ int ntsm_host_flatten_parallel_gz(const char *path, unsigned n_decoders, unsigne
 	return 0;
 }
 
-int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions, uint64_t max_chunks,
-		unsigned n_consumers, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases, uint64_t *n_parallel)
+int ntsm_host_early_ingest_hand_over(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions,
+		uint64_t max_chunks, unsigned n_consumers, uint64_t hand_over_after, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases,
+		uint64_t *n_parallel, uint64_t *n_rest)
 {
 	ntsm::EarlyIngest ei(path, n_parsers, n_decoders, block_bytes, 1000, chunk_positions, (size_t) max_chunks);
 	if (!ei.taken()) return 1;
 	std::mutex mu;
 	std::vector<uint8_t> all;
 	uint64_t reads = 0, bases = 0;
+	std::atomic<uint64_t> drained { 0 };
+	if (hand_over_after == 0) ei.hand_over();
 	std::vector<std::thread> pool;
 	for (unsigned t = 0; t < (n_consumers ? n_consumers : 1); ++t)
 		pool.emplace_back([&]() {
@@ -263,6 +266,7 @@ int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_deco
 				r += c->n_reads;
 				b += c->n_bases;
 				ei.recycle(std::move(c));
+				if (++drained == hand_over_after) ei.hand_over();
 			}
 			std::lock_guard<std::mutex> lk(mu);
 			all.insert(all.end(), mine.begin(), mine.end());
@@ -270,13 +274,43 @@ int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_deco
 			bases += b;
 		});
 	for (auto &th : pool) th.join();
+	const uint64_t through_chunks = reads;
+	uint64_t rest_reads = 0;
+	if (std::unique_ptr<ntsm::GzStream> rest = ei.release_stream()) {       /* what the stream still holds, read like the feeders' fall-back does */
+		ntsm::SeqReader rd;
+		if (rd.open_stream(std::move(rest))) {
+			std::vector<uint8_t> codes, valid;
+			for (int64_t l = rd.next(); l >= 0; l = rd.next()) {
+				const uint64_t ext = ntsm::pack2_extent(0, (uint64_t) l);
+				codes.assign(ext / 4 + 8, 0);
+				valid.assign(ext / 8 + 8, 0);
+				const uint64_t end = ntsm::pack2_append(codes.data(), valid.data(), 0, rd.seq_data(), (uint64_t) l);
+				for (uint64_t p = 0; p < end; ++p) {
+					const bool v = (valid[p >> 3] >> (p & 7)) & 1;
+					all.push_back(v ? (uint8_t) "ACGT"[(codes[p >> 2] >> (2 * (p & 3))) & 3] : (uint8_t) 'N');
+				}
+				all.push_back('N');
+				++reads;
+				bases += (uint64_t) l;
+				++rest_reads;
+			}
+		}
+	}
 	*text = (uint8_t *) malloc(all.size() + 1);
 	memcpy(*text, all.data(), all.size());
 	*n_text = all.size();
 	*n_reads = reads;
 	*n_bases = bases;
 	if (n_parallel) *n_parallel = ei.parallel_records();
-	return reads == ei.records() ? 0 : -2;
+	if (n_rest) *n_rest = rest_reads;
+	return through_chunks == ei.records() ? 0 : -2;
+}
+
+int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions, uint64_t max_chunks,
+		unsigned n_consumers, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases, uint64_t *n_parallel)
+{
+	return ntsm_host_early_ingest_hand_over(path, n_parsers, n_decoders, block_bytes, chunk_positions, max_chunks, n_consumers, ~0ull, text, n_text, n_reads,
+			n_bases, n_parallel, nullptr);
 }
 
 int ntsm_host_format_counts(const ntsm_sites *s, const uint64_t *counts, uint64_t total_kmers, char **out, size_t *len)

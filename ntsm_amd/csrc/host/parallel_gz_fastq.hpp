@@ -45,13 +45,17 @@ class ParallelGzFastq {
 public:
 	struct Result {
 		bool complete = false;      /* every byte of the stream was consumed by the parallel phase (and the stream ended cleanly) */
+		bool stopped = false;       /* the caller asked for the phase to end (stop_flag): the stream is positioned at a record boundary */
 		uint64_t records = 0;       /* records committed by the parallel phase */
 		uint64_t pieces = 0;
 		int status = 0;             /* complete: the stream's final status (1 clean, -1 error after the last piece) */
 	};
 	/* gz: an open stream nobody has read from yet.  After run(), !complete: gz is positioned (unread) at the record boundary
 	 * where the parallel phase stopped; read() continues from there. */
-	explicit ParallelGzFastq(GzStream *gz) : m_gz(gz) {}
+	/* stop_flag (optional): once it reads true no further piece is taken; the pieces in hand are finished and committed, the
+	 * unparsed end of the last one goes back to the stream like after a failed link (early_ingest.cpp hands the stream over
+	 * to the feeders that way) */
+	explicit ParallelGzFastq(GzStream *gz, const std::atomic<bool> *stop_flag = nullptr) : m_gz(gz), m_stop(stop_flag) {}
 
 	template <class Sink> Result run(const std::vector<Sink *> &sinks)
 	{
@@ -74,7 +78,8 @@ public:
 		}
 		for (uint64_t b = stop; b < m_nextSeq; ++b)
 			if (m_kept.count(b)) rest.push_back(std::move(m_kept[b]));
-		r.complete = rest.empty();
+		r.stopped = m_stopped;
+		r.complete = rest.empty() && !m_stopped;
 		r.status = m_gz->final_status();
 		if (!rest.empty()) m_gz->unread(std::move(rest), 0);
 		return r;
@@ -142,6 +147,7 @@ private:
 			{
 				std::lock_guard<std::mutex> lk(m_takeMu);
 				if (m_failSeq.load() != kNone || m_ended) break;     /* the parallel phase is over: the rest stays in the stream */
+				if (m_stop && m_stop->load(std::memory_order_relaxed)) { m_stopped = true; break; }
 				pc = m_gz->take();
 				if (!pc) { m_ended = true; break; }
 				b = m_nextSeq++;
@@ -228,7 +234,8 @@ private:
 	std::map<uint64_t, std::unique_ptr<GzStream::Piece>> m_kept;
 	std::atomic<uint64_t> m_failSeq { kNone };
 	uint64_t m_nextSeq = 0;
-	bool m_ended = false;
+	bool m_ended = false, m_stopped = false;              /* (under m_takeMu) */
+	const std::atomic<bool> *m_stop = nullptr;
 	std::atomic<uint64_t> m_records { 0 };
 	const std::string m_empty;
 };

@@ -651,9 +651,9 @@ def test_parallel_gzip_ingest_under_tsan(nt, tmp_path):
         # the early ingest on the same file (parsers -> packed chunks -> consumers, a small chunk budget so that parsers wait)
         if name != "cut.gz":
             outs = set()
-            for par, dec, block, cpos, budget, cons in ((4, 4, 1 << 20, 100000, 10, 3), (2, 3, 1 << 20, 1 << 20, 64, 1)):
-                p = subprocess.run([exe, path, "early", str(par), str(dec), str(block), str(cpos), str(budget), str(cons)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                   env=dict(env, NTSM_PARALLEL_CHUNK="20000"))
+            for par, dec, block, cpos, budget, cons, after in ((4, 4, 1 << 20, 100000, 10, 3, None), (2, 3, 1 << 20, 1 << 20, 64, 1, None), (4, 4, 1 << 20, 100000, 10, 3, 2)):
+                p = subprocess.run([exe, path, "early", str(par), str(dec), str(block), str(cpos), str(budget), str(cons)] + ([str(after)] if after is not None else []),
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, NTSM_PARALLEL_CHUNK="20000"))
                 assert p.returncode == 0, p.stderr.decode()[-3000:]
                 outs.add(p.stdout)
             assert len(outs) == 1 and b"reads=12000 " in outs.pop(), outs
@@ -708,6 +708,13 @@ def test_early_ingest_packs_the_same_reads(nt, tmp_path):
                         assert n_par == n_reads
                     if name == "wrapped.fq":
                         assert 0 < n_par < n_reads
+                # the consumers ask for the stream in the middle (EarlyIngest::hand_over): what went through the chunks plus
+                # what the stream still held is the same file; at 0 chunks nearly everything comes the second way
+                for after in ((0, 3, 40) if gz else (3,)):
+                    text2, n_reads2, n_bases2, _, n_rest = early_ingest(p, 4, 3, 1 << 20, 60_000, 8, 2, hand_over_after=after)
+                    assert n_reads2 == len(ref_e) and n_bases2 == int(ref_e[-1]) + 1 - len(ref_e), (name, gz, after, n_reads2, len(ref_e))
+                    assert collections.Counter(x for x in re.split(b"N+", text2) if x) == want, (name, gz, after)
+                    assert n_rest == 0 if not gz else (n_rest > 0 or after > 0), (name, gz, after, n_rest)
         fa = str(tmp_path / "x.fa")
         open(fa, "wb").write(b"".join(b">s%d\nACGTACGTAGCTAGCTAGCTAGCATCGAT\n" % i for i in range(100000)))
         assert early_ingest(fa) is None                                  # FASTA: not for this path (the ordinary one reads it)

@@ -30,8 +30,9 @@ int main(int argc, char **argv)
 	if (argc >= 8) {   /* parallel_tsan FILE early PARSERS DECODERS BLOCK CHUNK_POSITIONS BUDGET CONSUMERS: early_ingest.hpp */
 		uint8_t *text = nullptr;
 		uint64_t nt = 0, nreads = 0, nbases = 0, npar2 = 0;
-		int rc = ntsm_host_early_ingest(argv[1], (unsigned) atoi(argv[3]), (unsigned) atoi(argv[4]), strtoull(argv[5], nullptr, 10), strtoull(argv[6], nullptr, 10),
-				strtoull(argv[7], nullptr, 10), argc > 8 ? (unsigned) atoi(argv[8]) : 2u, &text, &nt, &nreads, &nbases, &npar2);
+		uint64_t nrest = 0;                                   /* a tenth argument: hand the gzip stream over after that many chunks */
+		int rc = ntsm_host_early_ingest_hand_over(argv[1], (unsigned) atoi(argv[3]), (unsigned) atoi(argv[4]), strtoull(argv[5], nullptr, 10), strtoull(argv[6], nullptr, 10),
+				strtoull(argv[7], nullptr, 10), argc > 8 ? (unsigned) atoi(argv[8]) : 2u, argc > 9 ? strtoull(argv[9], nullptr, 10) : ~0ull, &text, &nt, &nreads, &nbases, &npar2, &nrest);
 		if (rc) { fprintf(stderr, "rc=%d\n", rc); return 1; }
 		uint64_t letters = 0;
 		for (uint64_t i = 0; i < nt; ++i) letters += text[i] != 'N';
