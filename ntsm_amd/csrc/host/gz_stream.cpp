@@ -438,6 +438,19 @@ void GzStream::give_back(std::unique_ptr<Piece> p)
 std::unique_ptr<GzStream::Piece> GzStream::take()
 {
 	for (;;) {
+		if (!m_stash.empty()) {                                /* handed back by unread(): these have been through pop() already */
+			std::unique_ptr<Piece> p = std::move(m_stash.front());
+			m_stash.pop_front();
+			if (m_stashOff) {
+				const size_t off = std::min(m_stashOff, p->len);
+				memmove(p->data.data(), p->data.data() + off, p->len - off);
+				p->len -= off;
+				m_stashOff = 0;
+			}
+			if (p->len) return p;
+			give_back(std::move(p));
+			continue;
+		}
 		std::unique_ptr<Piece> p = pop();
 		if (!p) return nullptr;
 		if (p->len) return p;
@@ -450,6 +463,14 @@ std::unique_ptr<GzStream::Piece> GzStream::take()
 void GzStream::unread(std::deque<std::unique_ptr<Piece>> pieces, size_t offset)
 {
 	if (m_cur) { give_back(std::move(m_cur)); m_cur.reset(); }
+	/* what an earlier unread() left stays behind the new pieces (a second parallel phase on the same stream, early_ingest.cpp) */
+	if (!m_stash.empty() && m_stashOff) {
+		Piece &f = *m_stash.front();
+		const size_t off = std::min(m_stashOff, f.len);
+		memmove(f.data.data(), f.data.data() + off, f.len - off);
+		f.len -= off;
+	}
+	for (auto &p : m_stash) pieces.push_back(std::move(p));
 	m_stash = std::move(pieces);
 	m_stashOff = offset;
 }

@@ -276,24 +276,42 @@ int ntsm_host_early_ingest_hand_over(const char *path, unsigned n_parsers, unsig
 	for (auto &th : pool) th.join();
 	const uint64_t through_chunks = reads;
 	uint64_t rest_reads = 0;
-	if (std::unique_ptr<ntsm::GzStream> rest = ei.release_stream()) {       /* what the stream still holds, read like the feeders' fall-back does */
-		ntsm::SeqReader rd;
-		if (rd.open_stream(std::move(rest))) {
-			std::vector<uint8_t> codes, valid;
-			for (int64_t l = rd.next(); l >= 0; l = rd.next()) {
-				const uint64_t ext = ntsm::pack2_extent(0, (uint64_t) l);
-				codes.assign(ext / 4 + 8, 0);
-				valid.assign(ext / 8 + 8, 0);
-				const uint64_t end = ntsm::pack2_append(codes.data(), valid.data(), 0, rd.seq_data(), (uint64_t) l);
-				for (uint64_t p = 0; p < end; ++p) {
-					const bool v = (valid[p >> 3] >> (p & 7)) & 1;
-					all.push_back(v ? (uint8_t) "ACGT"[(codes[p >> 2] >> (2 * (p & 3))) & 3] : (uint8_t) 'N');
-				}
-				all.push_back('N');
-				++reads;
-				bases += (uint64_t) l;
-				++rest_reads;
+	if (std::unique_ptr<ntsm::GzStream> rest = ei.release_stream()) {
+		/* what the stream still holds, taken the way FingerPrint::countGzStream takes it: a second piece-parallel phase on the
+		 * same stream (it starts with what the first one handed back), then the sequential reader for what that leaves */
+		std::vector<uint8_t> codes, valid;
+		auto add_read = [&](const char *seq, uint64_t l) {
+			const uint64_t ext = ntsm::pack2_extent(0, l);
+			codes.assign(ext / 4 + 8, 0);
+			valid.assign(ext / 8 + 8, 0);
+			const uint64_t end = ntsm::pack2_append(codes.data(), valid.data(), 0, seq, l);
+			for (uint64_t p = 0; p < end; ++p) {
+				const bool v = (valid[p >> 3] >> (p & 7)) & 1;
+				all.push_back(v ? (uint8_t) "ACGT"[(codes[p >> 2] >> (2 * (p & 3))) & 3] : (uint8_t) 'N');
 			}
+			all.push_back('N');
+			++reads;
+			bases += l;
+			++rest_reads;
+		};
+		std::vector<CollectSink> sinks(n_parsers ? n_parsers : 1);
+		std::vector<CollectSink *> ptrs;
+		for (auto &s : sinks) { s.cap = 1u << 16; ptrs.push_back(&s); }
+		ntsm::ParallelGzFastq pg(rest.get());
+		const ntsm::ParallelGzFastq::Result r = pg.run(ptrs);
+		uint64_t got = 0;
+		for (auto &s : sinks) {
+			if (!s.lens.empty()) return -2;
+			for (auto &c : s.out) {
+				uint64_t off = 0;
+				for (uint64_t len : c.lens) { add_read((const char *) c.bases.data() + off, len); off += len + 1; ++got; }
+			}
+		}
+		if (got != r.records) return -2;
+		if (!r.complete) {
+			ntsm::SeqReader rd;
+			if (rd.open_stream(std::move(rest)))
+				for (int64_t l = rd.next(); l >= 0; l = rd.next()) add_read(rd.seq_data(), (uint64_t) l);
 		}
 	}
 	*text = (uint8_t *) malloc(all.size() + 1);
