@@ -956,6 +956,38 @@ def test_cli_parallel_gzip_ingest(nt, tmp_path):
                 assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr), (name, t, chunk, early)
                 if name == "wrapped.fq.gz" and not early:
                     assert b"parallel gzip: sequential after" in p.stderr
+    # The hand-over of the early ingest: a file whose inflate (one decoder thread: 1.9 GB/s of text) is still going on when the
+    # context is there -- the stream is given to the feeders at a record boundary and its rest parsed straight into the lanes.
+    # Same bytes as the single-thread run; the phase line shows that both halves carried records.
+    import re
+    big = str(tmp_path / "big.fq")
+    s.write_fastq(big, 0, 4_000_000, threads=8)
+    with open(big, "rb") as fi, open(big + ".gz", "wb") as fo:
+        co = zlib.compressobj(1, zlib.DEFLATED, 31)
+        while True:
+            d = fi.read(64 << 20)
+            if not d:
+                break
+            fo.write(co.compress(d))
+        fo.write(co.flush())
+    base = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", "8", big], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert base.returncode == 0
+    for dec, tail in (("1", False), ("1", True), ("6", False)):
+        path = big + ".gz"
+        if tail:                                                          # ... and with a last record that has no newline (sequential at the very end)
+            path = big + ".cut.gz"
+            raw = open(big, "rb").read()
+            open(path, "wb").write(member(raw[:-1], 1))
+        p = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", "8", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, NTSM_GZ_DECODERS=dec, NTSM_PHASE_TIMES="1"))
+        assert p.returncode == 0, p.stderr[-400:]
+        assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr), (dec, tail)
+        err = p.stderr.decode()
+        m_early = re.search(r"early ingest \(gzip[^)]*\) parsed (\d+) records", err)
+        m_rest = re.search(r"inflate\+parse\+count [0-9.e-]+ s \((\d+) records", err)
+        assert m_early and int(m_early.group(1)) > 0, err[-600:]
+        if dec == "1":
+            assert m_rest and int(m_rest.group(1)) > 0 and int(m_early.group(1)) < 4_000_000, err[-600:]
 
 
 def test_producer_lanes_share_one_context(nt, tmp_path):
