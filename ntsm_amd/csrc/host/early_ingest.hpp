@@ -11,7 +11,8 @@
  * submit them (Feeder::submitChunk) while the rest of the file is still being parsed.  What the parallel phase cannot take
  * (records that are not plain 4-line FASTQ) goes through the sequential reader into the same chunks, so the whole file is
  * covered either way; a file that cannot be opened is left to the ordinary path, which reports it like the reference.
- * The chunks in flight are bounded (a feeder that is not there yet makes the parsers wait).
+ * The chunks in flight are bounded (a feeder that is not there yet makes the parsers wait).  Once the feeders exist a gzip
+ * stream is handed over to them at a record boundary (hand_over / release_stream): its rest goes straight into the lanes.
  */
 #ifndef NTSM_EARLY_INGEST_HPP
 #define NTSM_EARLY_INGEST_HPP

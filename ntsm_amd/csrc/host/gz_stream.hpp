@@ -72,8 +72,9 @@ public:
 	 * next piece of text in stream order (len > 0), nullptr once the data has ended -- final_status() then says how: 1 = clean
 	 * end (or truncated file: every decodable byte was delivered, like gzread), -1 = invalid data / CRC / length.  Member
 	 * checks are made as the pieces pass, exactly as read() makes them.  One caller at a time (callers serialise).
-	 * give_back() recycles a piece's buffer; unread() puts pieces back IN FRONT of everything not yet taken, the first one
-	 * from byte `offset` on, for a following read() loop (the sequential reader after a parallel phase). */
+	 * give_back() recycles a piece's buffer; unread() puts pieces back IN FRONT of everything not yet taken (also in front
+	 * of what an earlier unread() left), the first one from byte `offset` on: the next read() or take() starts there (the
+	 * sequential reader after a parallel phase; a second parallel phase after the early ingest handed the stream over). */
 	std::unique_ptr<Piece> take();
 	int final_status() const { return m_final; }
 	void give_back(std::unique_ptr<Piece> p);

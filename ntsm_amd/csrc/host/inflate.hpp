@@ -58,7 +58,9 @@ public:
 	const uint8_t *in() const;          /* next unread input byte (valid after STREAM_END: bit buffer returned) */
 	uint64_t total_out() const { return m_total; }   /* bytes produced since reset() */
 
-	/* decode-table entry: bits 0-4 = bits to consume, 8-11 = extra bits (or sub-table bits), 12-15 = flags, 16-31 = value */
+	/* decode-table entry: bits 0-4 = bits to consume -- the code AND, for a length or distance, its extra bits (one shift takes
+	 * both; <= 11 + 13) --, 8-11 = how many of them are extra bits (pointer entries: sub-table bits), 12-15 = flags,
+	 * 16-31 = value (literal, base length / distance, sub-table offset) */
 	static constexpr uint32_t F_LIT = 0x8000u, F_EOB = 0x4000u, F_SUB = 0x2000u, F_ERR = 0x1000u;
 
 protected:
