@@ -287,7 +287,9 @@ __attribute__((target("avx2"))) void resolve_avx2(const uint8_t *lut, const uint
 		}
 		const __m256i first = _mm256_set1_epi16((short) sym[i]);
 		const __m256i da = _mm256_xor_si256(_mm256_sub_epi16(a, iota_a), first), db = _mm256_xor_si256(_mm256_sub_epi16(b, iota_b), first);
-		if (_mm256_testz_si256(_mm256_or_si256(da, db), _mm256_set1_epi16(-1))) {
+		/* (a stretch that runs over the top of the 16-bit range -- the window's last bytes followed by literals 0, 1, 2 ... --
+		 * compares equal modulo 65536 and is not a stretch of the table: sym[i] <= 65535 - 31) */
+		if (sym[i] <= 65535 - 31 && _mm256_testz_si256(_mm256_or_si256(da, db), _mm256_set1_epi16(-1))) {
 			_mm256_storeu_si256((__m256i *) (out + i), _mm256_loadu_si256((const __m256i *) (lut + sym[i])));
 			i += 32;
 			continue;
@@ -298,7 +300,7 @@ __attribute__((target("avx2"))) void resolve_avx2(const uint8_t *lut, const uint
 			i += 16;
 			continue;
 		}
-		if (_mm256_testz_si256(da, _mm256_set1_epi16(-1))) {
+		if (sym[i] <= 65535 - 15 && _mm256_testz_si256(da, _mm256_set1_epi16(-1))) {
 			_mm_storeu_si128((__m128i *) (out + i), _mm_loadu_si128((const __m128i *) (lut + sym[i])));
 			i += 16;
 			continue;

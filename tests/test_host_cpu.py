@@ -447,6 +447,26 @@ def test_parallel_gzip_decoder_matches_zlib(nt, tmp_path):
             parts += [co.compress(data[i:i + 70000]), co.flush(zlib.Z_SYNC_FLUSH if (i // 70000) % 2 else zlib.Z_FULL_FLUSH)]
         open(p, "wb").write(b"".join(parts) + co.flush())
         assert gunzip(p, 4) == (data, 0) and gunzip_parallel_stats()[0] > 5
+        # blocks that begin with a copy of the window's LAST bytes followed by the literals 0, 1, 2 ...: in a chunk that starts
+        # there the symbols read 0xFFFA .. 0xFFFF, 0, 1, 2 ... -- consecutive modulo 65536, yet not a stretch of the window
+        # (resolve()'s run test must not take them for one)
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        parts, plain = [], []
+        for i in range(40):
+            # more than a window of bytes above 0x7F between two units: the 0, 1, 2 ... of the previous one is out of reach, zlib codes them as literals
+            body = bytes(rng.getrandbits(8) | 0x80 for _ in range(rng.randrange(34000, 40000)))
+            tail = bytes(rng.getrandbits(8) | 0x80 for _ in range(rng.choice((3, 6, 12, 31))))
+            parts += [co.compress(body + tail), co.flush(zlib.Z_SYNC_FLUSH)]
+            again = tail + bytes(range(48))
+            parts.append(co.compress(again))
+            plain += [body, tail, again]
+        want = b"".join(plain)
+        open(p, "wb").write(b"".join(parts) + co.flush())
+        for chunk in (20000, 30000, 50000):
+            gunzip_parallel_chunk(chunk)
+            assert gunzip(p, 4) == (want, 0), chunk
+            assert gunzip_parallel_stats()[0] > 3
+        gunzip_parallel_chunk(8192)
         multi = _gz_member(data[:700000]) + _gz_member(b"") + _gz_member(data[700000:1500000], 1) + _gz_member(data[:10], 0) + _gz_member(data[1500000:], 9) + _gz_member(b"x")
         open(p, "wb").write(multi)
         assert gunzip(p, 4) == (data + data[:10] + b"x" if False else data[:700000] + data[700000:1500000] + data[:10] + data[1500000:] + b"x", 0)
