@@ -323,6 +323,22 @@ def test_block_parallel_ingest_under_tsan(nt, tmp_path):
     assert len(outs) == 2, outs
 
 
+def _skewed_payload(rng, n):
+    """Bytes whose frequencies fall off like Fibonacci numbers backwards (40 distinct values) with far repeats thrown in: the
+    Huffman codes zlib builds for it reach the 15-bit limit -- literal / length codes behind the decoder's 11-bit first table,
+    distance codes behind its 8-bit one, lengths and distances with all their extra bits."""
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    vals = list(range(33, 73))
+    out = bytearray(rng.choices(vals, weights=fib[::-1], k=n))
+    for _ in range(n // 4000):                                   # repeats at every distance up to the window, of every length
+        a, ln = rng.randrange(0, n - 70000), rng.choice((3, 4, 9, 17, 33, 67, 131, 258, 300))
+        b = min(n - ln, a + rng.choice((1, 2, 5, 40, 300, 5000, 20000, 32768 - 300)))
+        out[b:b + ln] = out[a:a + ln]
+    return bytes(out)
+
+
 def _gz_member(data, level=6, strategy=0, wbits=15, memlevel=8):
     import zlib
     co = zlib.compressobj(level, zlib.DEFLATED, 16 + wbits, memlevel, strategy)
@@ -344,7 +360,8 @@ def test_gzip_decoder_matches_zlib(nt, tmp_path):
     fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(150)),
                                           bytes(rng.choice(b"FFFF:,#") for _ in range(150))) for i in range(6000))
     payloads = [b"", b"A", b"ACGT" * 50000, bytes(rng.getrandbits(8) for _ in range(100000)), fq,
-                bytes(rng.choice(b"ab") for _ in range(150000)), b"\x00" * 2500000, bytes((i * 7 + (i >> 8)) & 0xFF for i in range(1 << 19))]
+                bytes(rng.choice(b"ab") for _ in range(150000)), b"\x00" * 2500000, bytes((i * 7 + (i >> 8)) & 0xFF for i in range(1 << 19)),
+                _skewed_payload(rng, 600000)]
     n = 0
     for pi, data in enumerate(payloads):
         for level in (0, 1, 6, 9):
@@ -418,7 +435,7 @@ def test_parallel_gzip_decoder_matches_zlib(nt, tmp_path):
     fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(150)),
                                           bytes(rng.choice(b"FFFF:,#") for _ in range(150))) for i in range(9000))
     payloads = [b"ACGT" * 200000, bytes(rng.getrandbits(8) for _ in range(300000)), fq, bytes(rng.choice(b"ab") for _ in range(400000)),
-                b"\x00" * 2500000, bytes((i * 7 + (i >> 8)) & 0xFF for i in range(1 << 20))]
+                b"\x00" * 2500000, bytes((i * 7 + (i >> 8)) & 0xFF for i in range(1 << 20)), _skewed_payload(rng, 900000)]
     try:
         n = spliced_total = 0
         for pi, data in enumerate(payloads):
