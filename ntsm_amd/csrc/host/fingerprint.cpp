@@ -2,7 +2,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -10,7 +9,6 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
-#include <sched.h>
 #include <sys/stat.h>
 
 #include "early_ingest.hpp"
@@ -263,36 +261,6 @@ bool big_gzip_input(const std::string &fn, uint64_t min_bytes)
 }
 /* from this many big .gz inputs on they are read side by side, one reader per file, instead of one after the other with the whole pool */
 size_t side_by_side_from(unsigned threads) { return std::max<size_t>(3, threads / 4); }
-
-/* CPUs this process may really use: the affinity mask, cut down to the cgroup's bandwidth quota (cgroup v2 cpu.max, v1
- * cpu.cfs_quota_us / cpu.cfs_period_us) -- a container on a 256-thread host is often granted 16 CPUs' worth of time, and
- * hardware_concurrency() says 256 all the same. */
-unsigned cpus_available()
-{
-	unsigned n = std::max(1u, std::thread::hardware_concurrency());
-	cpu_set_t set;
-	if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, (unsigned) std::max(1, CPU_COUNT(&set)));
-	auto quota = [](const char *path, const char *path_period) -> double {
-		FILE *f = fopen(path, "r");
-		if (!f) return 0;
-		char a[64] = "", b[64] = "";
-		const int got = fscanf(f, "%63s %63s", a, b);
-		fclose(f);
-		if (got < 1 || !strcmp(a, "max")) return 0;
-		double q = atof(a), p = got > 1 ? atof(b) : 0;
-		if (path_period) {
-			FILE *g = fopen(path_period, "r");
-			if (!g) return 0;
-			if (fscanf(g, "%63s", b) == 1) p = atof(b);
-			fclose(g);
-		}
-		return q > 0 && p > 0 ? q / p : 0;
-	};
-	double q = quota("/sys/fs/cgroup/cpu.max", nullptr);
-	if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
-	if (q > 0) n = std::min(n, (unsigned) std::max(1.0, q + 0.5));
-	return n;
-}
 } // namespace
 
 FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
@@ -329,12 +297,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 		size_t n_big_gz = 0;
 		for (const std::string &fn : m_opt.inputs) n_big_gz += big_gzip_input(fn, m_opt.gz_parallel_min_bytes) ? 1 : 0;
 		const bool side_by_side = !getenv("NTSM_ZLIB_ONLY") && n_big_gz >= side_by_side_from(m_opt.threads);
-		/* ... and it needs CPUs of its own: the start-up keeps a dozen threads busy (sites on 8, tables on 4, the runtime's
-		 * own), so on a host that grants only as many CPUs as -t asks for, parsing beside it just takes the time away from
-		 * it and pays the chunks' extra copy on top (pod with 16 CPUs, -t 16, 12.6 GB .gz: 0.93-1.00 s without, 1.01-1.07 s
-		 * with).  NTSM_EARLY=gz|plain|all forces it. */
-		const bool cpus_to_spare = getenv("NTSM_EARLY") || cpus_available() >= m_opt.threads + 8;
-		if (m_opt.early && cpus_to_spare && !side_by_side && m_opt.pack && m_opt.threads > 1 && !maybe_armed && m_opt.verbose <= 2 && !m_opt.inputs.empty()) {
+		if (m_opt.early && !side_by_side && m_opt.pack && m_opt.threads > 1 && !maybe_armed && m_opt.verbose <= 2 && !m_opt.inputs.empty()) {
 			const unsigned n_par = std::min(m_opt.threads, 16u);
 			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
 			const unsigned n_dec = m_opt.gz_decoders ? m_opt.gz_decoders : std::min(std::min(12u, hw), 2 * m_opt.threads);   /* fewer than later: the start-up has threads of its own */

@@ -948,9 +948,9 @@ def test_cli_parallel_gzip_ingest(nt, tmp_path):
         base = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert base.returncode == 0, base.stderr[-400:]
         for t, chunk in (("8", "20000"), ("3", "300000"), ("16", "0")):
-            for early in (True, False):                                 # parsed beside the start-up (early_ingest.hpp; forced: by default only with CPUs to spare) or on the ordinary path
+            for early in (True, False):                                 # parsed beside the start-up (early_ingest.hpp) or on the ordinary path
                 p = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", t, "-v", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                   env=dict(os.environ, NTSM_GZ_PARALLEL_MIN="1000", NTSM_GZ_CHUNK=chunk, **({"NTSM_EARLY": "gz"} if early else {"NTSM_NO_EARLY": "1"})))
+                                   env=dict(os.environ, NTSM_GZ_PARALLEL_MIN="1000", NTSM_GZ_CHUNK=chunk, **({} if early else {"NTSM_NO_EARLY": "1"})))
                 assert p.returncode == 0, p.stderr[-400:]
                 assert (b"early ingest (gzip" if early else b"parallel gzip:") in p.stderr     # took the parallel route
                 assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr), (name, t, chunk, early)
@@ -979,7 +979,7 @@ def test_cli_parallel_gzip_ingest(nt, tmp_path):
             raw = open(big, "rb").read()
             open(path, "wb").write(member(raw[:-1], 1))
         p = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", "8", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                           env=dict(os.environ, NTSM_GZ_DECODERS=dec, NTSM_PHASE_TIMES="1", NTSM_EARLY="gz"))   # (the default asks for spare CPUs first)
+                           env=dict(os.environ, NTSM_GZ_DECODERS=dec, NTSM_PHASE_TIMES="1"))
         assert p.returncode == 0, p.stderr[-400:]
         assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr), (dec, tail)
         err = p.stderr.decode()
