@@ -305,7 +305,10 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 			 * (medians of five, one box, interleaved: profiles/r04_gz3/decoders_ab.txt) */
 			const unsigned n_dec = m_opt.gz_decoders ? m_opt.gz_decoders : std::min(std::min(14u, hw), 2 * m_opt.threads);
 			const uint64_t chunk_pos = std::max<uint64_t>(4096, std::min<uint64_t>(std::max<uint64_t>(4096, m_opt.batch_bytes), lane_bytes(m_opt.threads))) & ~31ull;
-			const size_t max_chunks = (size_t) std::max<uint64_t>(4 * n_par, (4ull << 30) / (chunk_pos * 3 / 8 + 1));   /* 4 GiB of packed reads at most */
+			/* 1.5 GiB of packed reads at most (4 Gbases): a gzip stream is handed over when the context is
+			 * there, so the chunks only ever hold what was parsed during the start-up -- 0.6 GB for the 12.6 GB file at 12 GB/s
+			 * of text and 0.25 s; a slower start-up makes the parsers wait, not the host swap */
+			const size_t max_chunks = (size_t) std::max<uint64_t>(4 * n_par, (3ull << 29) / (chunk_pos * 3 / 8 + 1));
 			m_early.reset(new EarlyIngest(m_opt.inputs[0], n_par, n_dec, std::min<uint64_t>(m_opt.block_bytes, 2 * lane_bytes(m_opt.threads)),
 			                              m_opt.gz_parallel_min_bytes, chunk_pos, max_chunks, m_opt.early_kinds));
 			if (!m_early->taken()) m_early.reset();
