@@ -972,13 +972,13 @@ def test_cli_parallel_gzip_ingest(nt, tmp_path):
         fo.write(co.flush())
     base = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", "8", big], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert base.returncode == 0
-    for dec, tail in (("1", False), ("1", True), ("6", False)):
+    for dec, tail, t in (("1", False, "8"), ("1", True, "8"), ("6", False, "8"), ("1", False, "4")):   # -t 4: the feeders drain first, then parse
         path = big + ".gz"
         if tail:                                                          # ... and with a last record that has no newline (sequential at the very end)
             path = big + ".cut.gz"
             raw = open(big, "rb").read()
             open(path, "wb").write(member(raw[:-1], 1))
-        p = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", "8", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+        p = subprocess.run([exe, "-s", str(tmp_path / "s.fa"), "-t", t, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            env=dict(os.environ, NTSM_GZ_DECODERS=dec, NTSM_PHASE_TIMES="1"))
         assert p.returncode == 0, p.stderr[-400:]
         assert p.stdout == base.stdout and _summary(p.stderr) == _summary(base.stderr), (dec, tail)
