@@ -56,11 +56,14 @@ def parse_args(argv=None):
                     help="comma list of the secondary single-GPU measurements appended at N = 1 ('' or 'none': skip)")
     ap.add_argument("--long-reads", type=float, default=5e6)
     ap.add_argument("--stress-sites", type=float, default=1e6)
-    ap.add_argument("--stress-reads", type=float, default=2e8)
+    ap.add_argument("--stress-reads", type=float, default=1e9, help="configs[4] as BASELINE.json states it: 1e9 reads (151 GB resident)")
     ap.add_argument("--n10-full-sites", type=float, default=N_SITES)
-    ap.add_argument("--n10-full-reads", type=float, default=2e8)
+    ap.add_argument("--n10-full-reads", type=float, default=1e9)
     ap.add_argument("--e2e-reads", type=float, default=4e7, help="reads of the FASTQ the CLI leg counts (4e7 = 12.6 GB)")
     ap.add_argument("--e2e-threads", type=int, default=16)
+    ap.add_argument("--e2e-gz-single-reads", type=float, default=4e6,
+                    help="reads of the sample that is compressed by ONE ordinary single-threaded gzip -6 stream (4e6 = 1.26 GB of text)")
+    ap.add_argument("--e2e-qual-model", type=int, default=1, help="quality lines of the CLI legs' FASTQ: 1 Illumina-like 8-level binned, 0 constant 'I' (rounds 1-4)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch test: every rank prints its rank environment as one JSON line and exits before touching the GPU")
     return ap.parse_args(argv)
@@ -279,7 +282,15 @@ def config_sites(nt, torch, dev, local, tmp, label, what, sites_seed, n_sites, m
     t_create = time.perf_counter() - t0
     two_level = ctx.debug_stats()["two_level"]
     d_win = torch.from_numpy(s.windows).to(dev)
-    d_bases = torch.empty(n_reads * s.stride, dtype=torch.uint8, device=dev)
+    asked = n_reads
+    while True:
+        try:
+            d_bases = torch.empty(n_reads * s.stride, dtype=torch.uint8, device=dev)
+            break
+        except RuntimeError:                       # smaller GPU: halve until it fits, and say so in the leg
+            n_reads //= 2
+            if n_reads < 1000:
+                raise
     s.device_fill(d_win.data_ptr(), 0, n_reads, d_bases.data_ptr())
     torch.cuda.synchronize()
     reps = 2
@@ -295,7 +306,7 @@ def config_sites(nt, torch, dev, local, tmp, label, what, sites_seed, n_sites, m
     bases = n_reads * READ_LEN
     tj, note = pmc_constants(traffic_file)
     out = {"workload": "%s: %.6g sites (%d site 19-mers), %.3g synthetic 150 bp reads" % (what["name"], n_sites, len(sites.keys), n_reads),
-           "reads": n_reads, "site_kmers": len(sites.keys), "kernel_ms": ms, "gbases_per_s": bases / ms / 1e6,
+           "reads": n_reads, "reads_asked": asked, "site_kmers": len(sites.keys), "kernel_ms": ms, "gbases_per_s": bases / ms / 1e6,
            "roofline_frac": bases * (READ_LEN + 8) / READ_LEN / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel_form": "two-level" if two_level else "one-level",
            "hits_per_pass": t.total_hits // reps, "site_gen_and_load_s": t_sites, "create_s": t_create,
            "fabric_read_requests_per_base_from_pmc": tj.get("fabric_read_requests_per_base") if tj else None,
@@ -308,7 +319,7 @@ def config_sites(nt, torch, dev, local, tmp, label, what, sites_seed, n_sites, m
 
 
 def config_stress(nt, torch, dev, local, args, tmp):
-    """BASELINE.json configs[4]: 1 M sites (16 M site k-mers, 512 MiB key table), 150 bp reads resident in HBM."""
+    """BASELINE.json configs[4]: 1 M sites (16 M site k-mers, 512 MiB key table), 1e9 150 bp reads resident in HBM."""
     return config_sites(nt, torch, dev, local, tmp, "stress", {"name": "configs[4]", "check": not args.no_check}, 424242, int(args.stress_sites), 0,
                         int(args.stress_reads), STRESS_TRAFFIC_FILE)
 
@@ -380,12 +391,36 @@ def _crc32_combine(crc1, crc2, len2):
     return crc1 ^ crc2
 
 
-def _run_cli(exe, sites_path, threads, local, path, runs=2):
+def host_info():
+    """What the CLI legs' thread counts meet on this host: CPUs online, CPUs this process may run on, and the cgroup's CPU
+    quota (v2 cpu.max or v1 cfs quota / period) -- the pod that runs the driver's bench is granted 16 CPUs' worth of time on a
+    256-CPU box, and every host-side number of the e2e legs is bounded by that."""
+    info = {"cpus_online": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_cpu_max": None, "cgroup_cpus": None}
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        info["cgroup_cpu_max"] = " ".join(txt)
+        if txt[0] != "max":
+            info["cgroup_cpus"] = int(txt[0]) / int(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            info["cgroup_cpu_max"] = "%d %d" % (q, per)
+            if q > 0:
+                info["cgroup_cpus"] = q / per
+        except (OSError, ValueError):
+            pass
+    return info
+
+
+def _run_cli(exe, sites_path, threads, local, path, runs=2, env_extra=None):
     best = None
+    env = {k: v for k, v in os.environ.items() if k not in ("NTSM_FAST_EXIT", "NTSM_SYNC_EXIT", "NTSM_CLEAN_EXIT")}
+    env.update(NTSM_PHASE_TIMES="1", **(env_extra or {}))
     for _ in range(runs):                                  # second run: file certainly in the page cache
         t0 = time.perf_counter()
-        p = subprocess.run([exe, "-s", sites_path, "-t", str(threads), "-g", str(local), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                           env=dict(os.environ, NTSM_PHASE_TIMES="1"))
+        p = subprocess.run([exe, "-s", sites_path, "-t", str(threads), "-g", str(local), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         wall = time.perf_counter() - t0
         if p.returncode != 0:
             raise RuntimeError("ntsmCount failed: " + p.stderr.decode()[-400:])
@@ -397,25 +432,77 @@ def _run_cli(exe, sites_path, threads, local, path, runs=2):
     return wall, p, phases, (float(own[-1].split()[1]) if own else None)
 
 
+def _cli_both_exits(exe, sites_path, threads, local, path):
+    """The CLI on one input, whole process as the parent sees it, in both exit modes: the DEFAULT (the kernel's teardown of the
+    HIP process -- queues, pinned and device memory -- happens inside the process's exit, before the parent's wait() returns:
+    what the reference's plain `return 0` means) and NTSM_FAST_EXIT=1 (that teardown handed to a clone(CLONE_VM) child and
+    left out of the parent's sight: round 4's default, opt-in now).  `wall_s` is always the default mode's."""
+    wall, p, phases, cli_s = _run_cli(exe, sites_path, threads, local, path)
+    wall_fast, pf, _, cli_fast = _run_cli(exe, sites_path, threads, local, path, env_extra={"NTSM_FAST_EXIT": "1"})
+    assert pf.stdout == p.stdout, "counts.txt depends on the exit mode"
+    return wall, p, phases, cli_s, {"wall_s_fast_exit": wall_fast, "cli_reported_s_fast_exit": cli_fast,
+                                   "exit_mode_of_wall_s": "default: synchronous (teardown inside the process's exit)",
+                                   "exit_cost_s": wall - (cli_s or wall), "exit_cost_s_fast_exit": wall_fast - (cli_fast or wall_fast)}
+
+
+def _gzip_single_stream(src, dst):
+    """ONE ordinary gzip member written by ONE thread: the system's `gzip -6` when there is one, else Python's zlib (the same
+    DEFLATE level-6 strategy as `gzip -6` up to the implementation).  Returns (writer, Popen or None)."""
+    import shutil
+    gz = shutil.which("gzip")
+    if gz:
+        return "gzip -6 (GNU gzip, one thread)", subprocess.Popen([gz, "-6", "-c", src], stdout=open(dst, "wb"))
+    import threading
+    import zlib
+
+    def work():
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        with open(src, "rb") as f, open(dst, "wb") as o:
+            while True:
+                blk = f.read(8 << 20)
+                if not blk:
+                    break
+                o.write(co.compress(blk))
+            o.write(co.flush())
+    th = threading.Thread(target=work)
+    th.start()
+    th.wait = th.join
+    return "zlib.compressobj(6) in one thread (no gzip binary on this host)", th
+
+
+def _phase_seconds(phases, key, exclude=None):
+    for l in phases:
+        if key in l and not (exclude and exclude in l):
+            try:
+                return float(l.split(key)[1].split("s")[0])
+            except ValueError:
+                pass
+    return None
+
+
 def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
-    """File -> counts.txt through the CLI (build/ntsmCount -t N) on a generated plain FASTQ, the whole process timed;
-    its stdout must equal what the resident path prints for the same reads.  Then the same reads as ONE ordinary gzip member
-    (`e2e_cli_gz`: decoder pool + piece-parallel parse, gz_stream.hpp / parallel_gz_fastq.hpp): identical counts.txt."""
+    """File -> counts.txt through the CLI (build/ntsmCount -t N), the whole process timed, on a generated FASTQ whose quality
+    lines follow the Illumina-like 8-level model of synth.h (position-dependent decay, low scores in runs; gzip -6 ratio about
+    3.5:1 -- rounds 1-4 wrote 150 x 'I', 6:1 and one long copy per record for a DEFLATE decoder):
+      e2e_cli            the plain FASTQ; stdout must equal what the resident path prints for the same reads
+      e2e_cli_gz         the same reads as ONE gzip member written pigz-style (independent 64 MiB blocks, sync flushes)
+      e2e_cli_gz_single  a sample of the reads as ONE ordinary single-threaded `gzip -6` stream (no flush points: what a
+                         sequencing facility's gzip writes); stdout must equal the CLI's on the same sample as plain text
+    every leg in both exit modes (default synchronous; NTSM_FAST_EXIT=1), with the host's CPU grant stated."""
     n_reads = int(args.e2e_reads)
+    qm = int(args.e2e_qual_model)
+    host = host_info()
+    gen_threads = max(1, min(32, int(host["cgroup_cpus"] or 0) or (os.cpu_count() or 2) - 1))
     fq = os.path.join(tmp, "e2e.fq")
     t0 = time.perf_counter()
-    synth.write_fastq(fq, 0, n_reads, threads=max(1, min(32, (os.cpu_count() or 2) - 1)))
+    synth.write_fastq(fq, 0, n_reads, threads=gen_threads, qual_model=qm)
     t_gen = time.perf_counter() - t0
     size = os.path.getsize(fq)
     exe = os.path.join(ROOT, "build", "ntsmCount")
-    wall, p, phases, cli_s = _run_cli(exe, sites_path, args.e2e_threads, local, fq)
-    parse_s = None
-    for l in phases:
-        if "parse+count" in l and "inflate" not in l:
-            try:
-                parse_s = float(l.split("parse+count")[1].split("s")[0])
-            except ValueError:
-                pass
+    quality = {0: "constant 'I'", 1: "Illumina-like, 8-level binned, position-dependent decay (synth.h: ntsm_synth_qual_char)",
+               2: "Illumina-like, unbinned Phred 2..41"}.get(qm, str(qm))
+    wall, p, phases, cli_s, exits = _cli_both_exits(exe, sites_path, args.e2e_threads, local, fq)
+    parse_s = _phase_seconds(phases, "parse+count", exclude="inflate")
     # the same reads resident in HBM through the C ABI, printed by the same report code
     d_win = torch.from_numpy(synth.windows).to(dev)
     d_bases = torch.empty(n_reads * synth.stride, dtype=torch.uint8, device=dev)
@@ -432,42 +519,74 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
     assert rc == 0 and sha_cli == sha_res, "CLI counts.txt differs from the resident path's"
     bases = n_reads * READ_LEN
     out = {"workload": "build/ntsmCount -t %d on one plain FASTQ of %.3g reads (%.1f GB, page cache), hs_n10_like sites" % (args.e2e_threads, n_reads, size / 1e9),
+           "quality_lines": quality, "host": host,
            "reads": n_reads, "file_bytes": size, "wall_s": wall, "gbases_per_s": bases / wall / 1e9,
            "cli_reported_s": cli_s,       # inside the process; wall_s also holds its spawn from this (large) parent and its exit
            "parse_and_count_s": parse_s, "gbases_per_s_parse_and_count": bases / parse_s / 1e9 if parse_s else None,
+           "text_GB_per_s": size / wall / 1e9,
            "phases": phases, "fastq_gen_s": t_gen, "counts_sha256": sha_cli, "check": {"counts_txt_equals_resident_path": True}}
-    gz_out = None
+    out.update(exits)
+    gz_out = single_out = None
+    sample = os.path.join(tmp, "e2e_sample.fq")
+    sample_gz = sample + ".gz"
+    gz = os.path.join(tmp, "e2e.fq.gz")
     try:
-        gz = os.path.join(tmp, "e2e.fq.gz")
+        # the single-stream sample is compressed by ONE thread beside the pigz-style writer (neither is timed)
+        n_single = max(1000, min(n_reads, int(args.e2e_gz_single_reads)))
+        synth.write_fastq(sample, 0, n_single, threads=gen_threads, qual_model=qm)
+        t0s = time.perf_counter()
+        writer, job = _gzip_single_stream(sample, sample_gz)
         t0 = time.perf_counter()
-        gz_size = pigz_like(fq, gz, threads=max(1, min(48, (os.cpu_count() or 2) - 1)))
+        gz_size = pigz_like(fq, gz, threads=max(1, min(48, int(host["cgroup_cpus"] or 0) or (os.cpu_count() or 2) - 1)))
         t_gz = time.perf_counter() - t0
         os.unlink(fq)
-        wall, pz, phases, cli_s = _run_cli(exe, sites_path, args.e2e_threads, local, gz)
+        job.wait()
+        t_single = time.perf_counter() - t0s
+        if getattr(job, "returncode", 0):
+            raise RuntimeError("gzip -6 of the sample failed: %r" % job.returncode)
+
+        wall, pz, phases, cli_s, exits = _cli_both_exits(exe, sites_path, args.e2e_threads, local, gz)
         os.unlink(gz)
         assert hashlib.sha256(pz.stdout).hexdigest() == sha_cli, "counts.txt of the .gz run differs from the plain FASTQ's"
-        infl = None
         early = any("early ingest" in l for l in phases)      # then the inflate started with the process and that line covers only the stream's rest
-        for l in phases:
-            if "inflate+parse+count" in l and not early:
-                try:
-                    infl = float(l.split("inflate+parse+count")[1].split("s")[0])
-                except ValueError:
-                    pass
+        infl = None if early else _phase_seconds(phases, "inflate+parse+count")
         gz_out = {"workload": "build/ntsmCount -t %d on the same reads as ONE gzip member (%.2f GB; level 6, written pigz-style in 64 MiB blocks)" % (args.e2e_threads, gz_size / 1e9),
+                  "quality_lines": quality, "host": host, "compression_ratio": size / gz_size,
                   "reads": n_reads, "file_bytes": gz_size, "text_bytes": size, "wall_s": wall, "gbases_per_s": bases / wall / 1e9, "cli_reported_s": cli_s,
+                  "text_GB_per_s": size / wall / 1e9,
                   "inflate_parse_count_s": infl, "gbases_per_s_inflate_parse_count": bases / infl / 1e9 if infl else None,
                   "text_GB_per_s_inflate_parse_count": size / infl / 1e9 if infl else None, "phases": phases, "gzip_s": t_gz,
                   "check": {"counts_txt_equals_plain_fastq_run": True}}
+        gz_out.update(exits)
+
+        # ONE ordinary gzip -6 stream of the sample; its counts.txt must equal the CLI's on the same sample as plain text
+        s_size, s_gz_size = os.path.getsize(sample), os.path.getsize(sample_gz)
+        _, pp, _, _ = _run_cli(exe, sites_path, args.e2e_threads, local, sample, runs=1)
+        os.unlink(sample)
+        wall, ps, phases, cli_s, exits = _cli_both_exits(exe, sites_path, args.e2e_threads, local, sample_gz)
+        assert ps.stdout == pp.stdout, "counts.txt of the single-stream .gz run differs from the plain sample's"
+        sb = n_single * READ_LEN
+        early = any("early ingest" in l for l in phases)
+        infl = None if early else _phase_seconds(phases, "inflate+parse+count")
+        single_out = {"workload": "build/ntsmCount -t %d on the first %.3g reads as ONE ordinary single-threaded gzip stream (%.2f GB)" % (args.e2e_threads, n_single, s_gz_size / 1e9),
+                      "writer": writer, "quality_lines": quality, "host": host, "compression_ratio": s_size / s_gz_size,
+                      "reads": n_single, "file_bytes": s_gz_size, "text_bytes": s_size, "wall_s": wall, "gbases_per_s": sb / wall / 1e9,
+                      "cli_reported_s": cli_s, "text_GB_per_s": s_size / wall / 1e9,
+                      "inflate_parse_count_s": infl, "text_GB_per_s_inflate_parse_count": s_size / infl / 1e9 if infl else None,
+                      "phases": phases, "gzip_s": t_single, "counts_sha256": hashlib.sha256(ps.stdout).hexdigest(),
+                      "check": {"counts_txt_equals_plain_sample_run": True}}
+        single_out.update(exits)
     except AssertionError:
         raise
     except Exception as e:
-        gz_out = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        err = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        gz_out = gz_out or err
+        single_out = single_out or err
     finally:
-        for f in (fq, os.path.join(tmp, "e2e.fq.gz")):
+        for f in (fq, gz, sample, sample_gz):
             if os.path.exists(f):
                 os.unlink(f)
-    return out, gz_out
+    return out, gz_out, single_out
 
 
 def run_rank(args):
@@ -705,7 +824,7 @@ def run_rank(args):
                     elif name == "n10_full":
                         other["n10_full"] = config_n10_full(ntsm_amd, torch, dev, local, args, tmp)
                     elif name == "e2e":
-                        other["e2e_cli"], other["e2e_cli_gz"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp)
+                        other["e2e_cli"], other["e2e_cli_gz"], other["e2e_cli_gz_single"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp)
                     else:
                         continue
                 except AssertionError:
@@ -716,6 +835,13 @@ def run_rank(args):
                 if key in other:
                     other[key]["leg_wall_s"] = time.perf_counter() - t0
             out["other_configs"] = other
+            # the headline's site set is a stand-in: the real human_sites_n10.fa (absent) holds 0.58 - 2.50 M distinct k-mers
+            # (SURVEY.md 8a); configs[1] above sits at 1.54 M, n10_full is the upper bound -- the span a user of the real file meets
+            nf = other.get("n10_full", {})
+            if nf.get("roofline_frac"):
+                out["roofline"]["frac_range"] = sorted([nf["roofline_frac"], out["roofline"]["frac"]])
+                out["roofline"]["frac_range_note"] = ("[n10_full (%d site k-mers: upper bound of the absent human_sites_n10.fa), configs[1] stand-in "
+                                                      "(%d site k-mers)], at %.3g and %.3g resident reads" % (nf["site_kmers"], len(sites.keys), nf["reads"], n_reads))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -51,6 +51,8 @@ int ntsm_host_gunzip(const char *path, int engine, unsigned chunk, uint8_t **out
  * (0 = the default 1 MiB; files shorter than two chunks are decoded in order).  stats, if not NULL, receives what the last
  * ntsm_host_gunzip call with engine >= 2 did: [0] chunks spliced in, [1] chunks dropped (no block start found in their
  * range, start not confirmed by the in-order decoder, or decoding failed). */
+void ntsm_host_gunzip_parallel_chunk(uint64_t bytes);
+void ntsm_host_gunzip_parallel_stats(uint64_t stats[2]);
 /* Test hook for the parallel gzip ingest (parallel_gz_fastq.hpp over gz_stream.hpp): n_decoders decoder threads inflate
  * `path`, n_parsers threads parse the pieces (sinks of sink_bytes each), the sequential reader finishes what the parallel
  * phase left.  Reads come back piece by piece; INSIDE a piece the records carried over from the previous piece may stand
@@ -70,8 +72,13 @@ int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_deco
 int ntsm_host_early_ingest_hand_over(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions,
 		uint64_t max_chunks, unsigned n_consumers, uint64_t hand_over_after, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases,
 		uint64_t *n_parallel, uint64_t *n_rest);
-void ntsm_host_gunzip_parallel_chunk(uint64_t bytes);
-void ntsm_host_gunzip_parallel_stats(uint64_t stats[2]);
+/* Test hook: the n-th chunk allocation of an early ingest from now on fails (0 = off).  The hooks above then return -3:
+ * an allocation failure must surface as a failed run, never as a shorter one (the CLI exits 1 with a message and prints no
+ * counts, like the reference for a file it cannot read: src/FingerPrint.hpp:51-57). */
+void ntsm_host_debug_early_alloc_fail(long nth);
+/* Test hook: the longest unparsed rest a piece of the piece-parallel gzip parse may carry into the next link (0 = the default
+ * 256 MiB); a piece whose rest is longer commits what it parsed and ends the parallel phase there. */
+void ntsm_host_debug_gz_max_tail(uint64_t bytes);
 /* Block-parallel variant for plain 4-line FASTQ (ntsm_amd/csrc/host/parallel_fastq.hpp), for tests: the records
  * the parallel phase commits (in file order) followed by what the sequential reader yields from *resume on.
  * Returns 0, 1 if the file is not eligible (callers use ntsm_host_flatten), -1 if it cannot be opened.

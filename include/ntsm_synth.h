@@ -57,6 +57,13 @@ int ntsm_synth_short_write_fastq(const ntsm_synth_short *p, const uint8_t *windo
 /* The same file (plain output), written by n_threads threads with pwrite() at computed offsets. */
 int ntsm_synth_short_write_fastq_mt(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
 		uint64_t n_reads, const char *path, unsigned n_threads);
+/* Both with a quality model (ntsm_synth_qual_char in synth.h: 0 = constant 'I' as above, 1 = Illumina-like -- position-dependent
+ * decay, 20+ distinct scores, low scores in short runs; the text then compresses ~3.5:1 instead of 6:1).  The sequence lines,
+ * hence the counts, do not depend on the model. */
+int ntsm_synth_short_write_fastq_q(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
+		uint64_t n_reads, const char *path, unsigned qual_model);
+int ntsm_synth_short_write_fastq_mt_q(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
+		uint64_t n_reads, const char *path, unsigned n_threads, unsigned qual_model);
 int ntsm_synth_long_write_fastq(const ntsm_synth_long *p, const uint8_t *windows, const uint32_t *qtable257,
 		uint64_t r0, uint64_t n_reads, const char *path);
 

@@ -106,6 +106,8 @@ _sig(HO, "ntsm_host_early_ingest", C.c_int, [C.c_char_p, C.c_uint, C.c_uint, C.c
 _sig(HO, "ntsm_host_early_ingest_hand_over", C.c_int, [C.c_char_p, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, u64p, u64p, u64p, u64p])
 _sig(HO, "ntsm_host_gunzip_parallel_chunk", None, [C.c_uint64])
 _sig(HO, "ntsm_host_gunzip_parallel_stats", None, [u64p])
+_sig(HO, "ntsm_host_debug_early_alloc_fail", None, [C.c_long])
+_sig(HO, "ntsm_host_debug_gz_max_tail", None, [C.c_uint64])
 _sig(HO, "ntsm_host_flatten_parallel", C.c_int, [C.c_char_p, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, u64p])
 _sig(HO, "ntsm_host_pack2_append", C.c_uint64, [u8p, u8p, C.c_uint64, u8p, C.c_uint64, C.c_int])
 _sig(HO, "ntsm_host_pack2_impl", C.c_char_p, [])
@@ -129,6 +131,7 @@ _sig(SY, "ntsm_synth_long_fill_device", C.c_int, [C.POINTER(SynthLongParams), C.
                                                   C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p])
 _sig(SY, "ntsm_synth_short_write_fastq", C.c_int, [C.POINTER(SynthShortParams), u8p, C.c_uint64, C.c_uint64, C.c_char_p])
 _sig(SY, "ntsm_synth_short_write_fastq_mt", C.c_int, [C.POINTER(SynthShortParams), u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint])
+_sig(SY, "ntsm_synth_short_write_fastq_mt_q", C.c_int, [C.POINTER(SynthShortParams), u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint, C.c_uint])
 _sig(SY, "ntsm_synth_long_write_fastq", C.c_int, [C.POINTER(SynthLongParams), u8p, u32p, C.c_uint64, C.c_uint64, C.c_char_p])
 
 KEYS_CANONICAL, KEYS_HASH64 = 0, 1
@@ -218,6 +221,16 @@ def gunzip(path, engine=0, chunk=1 << 16):
 def gunzip_parallel_chunk(n_bytes):
     """Compressed bytes per chunk of the parallel plain-gzip decoder (engine >= 2); 0 = default."""
     HO.ntsm_host_gunzip_parallel_chunk(C.c_uint64(n_bytes))
+
+
+def debug_early_alloc_fail(nth):
+    """Test hook: the nth chunk allocation of an early ingest from now on fails (0 = off)."""
+    HO.ntsm_host_debug_early_alloc_fail(C.c_long(nth))
+
+
+def debug_gz_max_tail(n_bytes):
+    """Test hook: longest unparsed rest a piece of the piece-parallel gzip parse may carry on (0 = default 256 MiB)."""
+    HO.ntsm_host_debug_gz_max_tail(C.c_uint64(n_bytes))
 
 
 def gunzip_parallel_stats():
@@ -484,9 +497,10 @@ class SynthShort:
         if rc:
             raise NtsmError("device fill failed: %d" % rc)
 
-    def write_fastq(self, path, r0, n_reads, threads=1):
-        """FASTQ of reads [r0, r0 + n_reads); threads > 1: the same bytes written by several threads (plain output)."""
-        rc = SY.ntsm_synth_short_write_fastq_mt(C.byref(self.params), _p(self.windows, u8p), r0, n_reads, os.fsencode(path), threads)
+    def write_fastq(self, path, r0, n_reads, threads=1, qual_model=0):
+        """FASTQ of reads [r0, r0 + n_reads); threads > 1: the same bytes written by several threads (plain output).
+        qual_model 0: constant 'I'; 1: Illumina-like qualities (synth.h: ntsm_synth_qual_char)."""
+        rc = SY.ntsm_synth_short_write_fastq_mt_q(C.byref(self.params), _p(self.windows, u8p), r0, n_reads, os.fsencode(path), threads, qual_model)
         if rc:
             raise NtsmError("write_fastq failed: %d" % rc)
 

@@ -17,13 +17,16 @@ namespace ntsm {
 
 PackedChunk::~PackedChunk() { free(mem); }
 
+static std::atomic<long> g_failAlloc { 0 };                  /* test hook: countdown to a failing chunk allocation */
+void EarlyIngest::debug_fail_allocation(long nth) { g_failAlloc.store(nth); }
+
 void PackedChunk::reserve(uint64_t positions)
 {
 	if (cap >= positions) return;
 	free(mem);
 	const size_t huge = 2u << 20;
 	const size_t bytes = ((size_t) (positions / 4 + positions / 8) + huge - 1) & ~(huge - 1);
-	mem = aligned_alloc(huge, bytes);
+	mem = (g_failAlloc.load() > 0 && g_failAlloc.fetch_sub(1) == 1) ? nullptr : aligned_alloc(huge, bytes);
 	if (!mem) { cap = 0; codes = valid = nullptr; return; }
 	(void) madvise(mem, bytes, MADV_HUGEPAGE);
 	codes = (uint8_t *) mem;
@@ -40,7 +43,7 @@ void EarlyIngest::Sink::feed(const char *seq, uint64_t len)
 {
 	if (!m_cur) {
 		m_cur = m_owner->blank(pack2_extent(0, len));
-		if (!m_cur) return;                                    /* the run is being abandoned */
+		if (!m_cur) return;                                    /* the run is being abandoned (by its owner, or after fail(): then failed() says so) */
 	}
 	m_cur->pos = pack2_append(m_cur->codes, m_cur->valid, m_cur->pos, seq, len);
 	m_cur->n_bases += len;
@@ -75,10 +78,27 @@ std::unique_ptr<PackedChunk> EarlyIngest::blank(uint64_t min_positions)
 	const uint64_t want = std::max<uint64_t>(m_chunkPositions, (min_positions + 31) & ~31ull);
 	if (!c) c.reset(new PackedChunk());
 	c->reserve(want);
-	if (!c->cap) return nullptr;
+	if (!c->cap) {                                             /* out of memory: not an abandon -- reads would be lost silently */
+		{
+			std::lock_guard<std::mutex> lk(m_mu);
+			--m_out;
+		}
+		fail("cannot allocate a " + std::to_string((want / 4 + want / 8) >> 20) + " MiB chunk for the early ingest of " + m_path);
+		return nullptr;
+	}
 	c->pos = c->n_bases = 0;
 	c->n_reads = 0;
 	return c;
+}
+
+void EarlyIngest::fail(const std::string &what)
+{
+	{
+		std::lock_guard<std::mutex> lk(m_mu);
+		if (!m_failed.load()) { m_error = what; m_failed.store(true); }
+		m_abandon = true;                                      /* every parser stops at its next chunk */
+	}
+	m_cv.notify_all();
 }
 
 void EarlyIngest::publish(std::unique_ptr<PackedChunk> c)
@@ -170,9 +190,10 @@ void EarlyIngest::run()
 	if (m_plain) {
 		const ParallelFastq::Result r = m_plain->run(ptrs);
 		m_parallelRecords = r.records;
-		if (!r.complete) {
+		if (!r.complete && !m_failed.load()) {
 			SeqReader rd;
 			if (rd.open(m_path, r.resume)) sequential(rd);
+			else fail("cannot reopen " + m_path + " for the records the block-parallel phase left");
 		}
 		m_plain.reset();
 	} else {
@@ -181,9 +202,10 @@ void EarlyIngest::run()
 		m_parallelRecords = r.records;
 		if (r.stopped) {
 			m_rest = std::move(m_gz);                            /* the consumers take it from here (release_stream) */
-		} else if (!r.complete) {
+		} else if (!r.complete && !m_failed.load()) {
 			SeqReader rd;
 			if (rd.open_stream(std::move(m_gz))) sequential(rd);
+			else fail("cannot continue reading " + m_path + " after the piece-parallel phase");
 		}
 		m_gz.reset();
 	}

@@ -65,6 +65,13 @@ public:
 	 * gigabytes of first-touched memory less).  No effect on a plain file. */
 	void hand_over() { m_handOver.store(true); }
 	std::unique_ptr<GzStream> release_stream();        /* null: the whole file went through the chunks */
+	/* true once something went wrong that LOSES reads (a chunk could not be allocated, the rest of the file could not be
+	 * reopened): valid after next() returned false / release_stream(); the caller must not print counts (the reference's
+	 * contract for a file it cannot read is exit(1) with a message, src/FingerPrint.hpp:51-57) */
+	bool failed() const { return m_failed.load(); }
+	const std::string &error() const { return m_error; }
+	/* test hook: the n-th chunk allocation from now on fails (0 = off); compiled in, armed only through the host C API */
+	static void debug_fail_allocation(long nth);
 	/* statistics for the phase line, valid after next() returned false */
 	uint64_t records() const { return m_records; }
 	uint64_t parallel_records() const { return m_parallelRecords; }
@@ -106,6 +113,9 @@ private:
 	size_t m_out = 0;                                  /* chunks that exist outside m_free */
 	bool m_done = false, m_abandon = false;
 	std::atomic<bool> m_handOver { false };
+	std::atomic<bool> m_failed { false };
+	std::string m_error;                               /* written once, under m_mu, before m_failed is set */
+	void fail(const std::string &what);                /* records the first error and abandons the run */
 	std::unique_ptr<GzStream> m_rest;                  /* set by run() when the parallel phase ended on hand_over() */
 	uint64_t m_records = 0, m_parallelRecords = 0;
 	std::string m_how;

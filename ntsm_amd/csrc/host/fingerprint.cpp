@@ -561,7 +561,7 @@ void FingerPrint::drainEarly()
 		});
 	std::unique_ptr<GzStream> rest = m_early->release_stream();   /* waits for the parsers to finish what they hold */
 	const auto t2 = std::chrono::steady_clock::now();
-	if (rest) {
+	if (rest && !m_early->failed()) {
 		if (n_drain < n_par) {
 			countGzStream(std::move(rest), m_opt.inputs[0], n_drain, n_par - n_drain);
 			for (auto &th : pool) th.join();
@@ -572,6 +572,10 @@ void FingerPrint::drainEarly()
 		pool.clear();
 	}
 	for (auto &th : pool) th.join();
+	if (m_early->failed()) {                                    /* reads were lost (no memory for a chunk, the file's rest unreadable): never print counts */
+		std::cerr << "ntsmCount: " << m_early->error() << ": " << ntsm_strerror(NTSM_ERR_NOMEM) << std::endl;
+		exit(1);
+	}
 	if (m_opt.phase_times)
 		std::cerr << "[phase] " << m_opt.inputs[0] << ": early ingest (" << m_early->how() << ") parsed " << m_early->records() << " records ("
 		          << m_early->parallel_records() << " in parallel) in " << m_early->parse_seconds() << " s beside the start-up; lanes "

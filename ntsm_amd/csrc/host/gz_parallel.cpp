@@ -95,6 +95,15 @@ std::unique_ptr<GzStream::Parallel::Chunk> GzStream::Parallel::take()
 	return c;
 }
 
+void GzStream::Parallel::drop(std::unique_ptr<Chunk> c)
+{
+	if (!c) return;
+	std::lock_guard<std::mutex> lk(m_mu);
+	if (c->sym.capacity()) m_bufPool.push_back(std::move(c->sym));
+	--spliced;
+	++dropped;
+}
+
 void GzStream::Parallel::resolve_async(std::unique_ptr<Chunk> c, const uint8_t *window, Piece *piece)
 {
 	Resolve r;

@@ -33,6 +33,9 @@ struct GzStream::Parallel {
 	 * beyond that bit; ~0ull: no chunk left. */
 	uint64_t target(uint64_t pos);
 	std::unique_ptr<Chunk> take();                     /* the chunk target() just matched */
+	/* a taken chunk that is not spliced in after all (the member has no full window yet): counted as dropped, not as
+	 * spliced, and its symbol buffer goes back to the pool */
+	void drop(std::unique_ptr<Chunk> c);
 	/* hand a spliced chunk to the workers: piece (already queued in order, ready = false) gets its bytes and CRC */
 	void resolve_async(std::unique_ptr<Chunk> c, const uint8_t *window, Piece *piece);
 	size_t spliced = 0, dropped = 0;                   /* statistics */

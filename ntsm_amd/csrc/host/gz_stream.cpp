@@ -238,7 +238,10 @@ void GzStream::produce()
 				const uint64_t pos = inf.bit_pos(m_map);
 				if (par->target(pos) != pos) continue;
 				std::unique_ptr<Parallel::Chunk> c = par->take();
-				if (inf.total_out() < kWindow || out < kWindow) continue;   /* starts here, but this member has no full window yet: dropped */
+				if (inf.total_out() < kWindow || out < kWindow) {           /* starts here, but this member has no full window yet: dropped */
+					par->drop(std::move(c));
+					continue;
+				}
 				const uint8_t *const win = work.data() + out - kWindow;
 				const size_t n = c->n_sym;
 				const uint16_t *const sym = c->sym.data() + kWindow;

@@ -274,6 +274,7 @@ int ntsm_host_early_ingest_hand_over(const char *path, unsigned n_parsers, unsig
 			bases += b;
 		});
 	for (auto &th : pool) th.join();
+	if (ei.failed()) return -3;                                 /* reads were lost: what FingerPrint::drainEarly turns into exit(1) */
 	const uint64_t through_chunks = reads;
 	uint64_t rest_reads = 0;
 	if (std::unique_ptr<ntsm::GzStream> rest = ei.release_stream()) {
@@ -323,6 +324,10 @@ int ntsm_host_early_ingest_hand_over(const char *path, unsigned n_parsers, unsig
 	if (n_rest) *n_rest = rest_reads;
 	return through_chunks == ei.records() ? 0 : -2;
 }
+
+void ntsm_host_debug_gz_max_tail(uint64_t bytes) { ntsm::ParallelGzFastq::set_max_tail((size_t) bytes); }
+
+void ntsm_host_debug_early_alloc_fail(long nth) { ntsm::EarlyIngest::debug_fail_allocation(nth); }
 
 int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions, uint64_t max_chunks,
 		unsigned n_consumers, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases, uint64_t *n_parallel)

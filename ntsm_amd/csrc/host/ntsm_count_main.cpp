@@ -79,27 +79,41 @@ static bool parse(const char *arg, T &out)
 /* What is left once everything is printed is the kernel's work: unmapping the queues of the HIP runtime, releasing its
  * pinned and device memory, the address space -- 0.10-0.15 s on the MI355X box for this process, all of it inside exit(2),
  * i.e. between `Time:` and the moment the caller's wait() returns (tools/exit_cost.hip: 0.06-0.09 s for a process that
- * only initialised the runtime, +4 ms per stream, +0.1 s per GB of pinned memory).  That work starts when the LAST user of
- * the address space goes.  So the last user is made somebody else: a child that shares the address space (clone(CLONE_VM),
- * its own copy of the descriptor table, so the /dev/kfd and render-node files are released by it as well), closes its
- * copies of stdin/stdout/stderr, waits until this process is gone and then leaves -- the teardown happens there, beside
- * whatever the caller does next (measured: the next run's start does not wait for it, profiles/r04_exit/).  The child is
- * re-parented to the session's reaper like any daemonised process.  NTSM_SYNC_EXIT=1: keep the teardown inside this
- * process's exit; NTSM_CLEAN_EXIT=1: run the destructors as well. */
+ * only initialised the runtime, +4 ms per stream, +0.1 s per GB of pinned memory).  The reference simply returns from main
+ * (src/ntSeqMatchCount.cpp:182-185) and so does this tool BY DEFAULT: when the caller's wait() returns, the process, its
+ * HBM, its pinned memory and its /dev/kfd handles are gone.
+ *
+ * NTSM_FAST_EXIT=1 (opt-in, round 4's default) moves that work out of the caller's sight: the teardown starts when the LAST
+ * user of the address space goes, so the last user is made somebody else -- a child that shares the address space
+ * (clone(CLONE_VM), its own copy of the descriptor table, so the /dev/kfd and render-node files are released by it as well),
+ * closes its copies of stdin/stdout/stderr, waits until this process is gone and then leaves.  What that costs, and why it is
+ * not the default: for 0.1-0.2 s after the CLI has "finished" a stray process still owns the context's HBM, pinned memory and
+ * queues (a cgroup / Slurm step clean-up or a back-to-back run sees it), and the child is re-parented to whatever reaps
+ * orphans -- under a PID 1 that never waits (a container without an init) every run leaves a zombie.  It is refused when this
+ * process's parent is PID 1 for that reason.  The child makes raw system calls only (no glibc wrapper: it shares the parent
+ * thread's TLS and must not write its errno) on a static stack.  NTSM_CLEAN_EXIT=1: run the destructors as well. */
+static inline long raw_syscall3(long nr, long a, long b, long c)
+{
+	long ret;
+	__asm__ volatile("syscall" : "=a"(ret) : "a"(nr), "D"(a), "S"(b), "d"(c) : "rcx", "r11", "memory");
+	return ret;
+}
+
 static int teardown_child(void *arg)
 {
 	const long parent = (long) (intptr_t) arg;
-	for (int fd = 0; fd < 3; ++fd) syscall(SYS_close, fd);   /* raw system calls only: this shares the parent's memory */
+	for (long fd = 0; fd < 3; ++fd) raw_syscall3(SYS_close, fd, 0, 0);
 	struct timespec ts = { 0, 100000 };
-	for (int i = 0; i < 20000 && syscall(SYS_getppid) == parent; ++i) syscall(SYS_nanosleep, &ts, nullptr);   /* <= 2 s */
-	syscall(SYS_exit_group, 0);
+	for (int i = 0; i < 20000 && raw_syscall3(SYS_getppid, 0, 0, 0) == parent; ++i) raw_syscall3(SYS_nanosleep, (long) &ts, 0, 0);   /* <= 2 s */
+	raw_syscall3(SYS_exit_group, 0, 0, 0);
 	return 0;
 }
 
-static void hand_over_teardown()
+static bool hand_over_teardown()
 {
+	if (getppid() == 1) return false;                      /* nobody we can count on to reap the child */
 	alignas(64) static char stack[64 << 10];
-	(void) clone(teardown_child, stack + sizeof stack, CLONE_VM | CLONE_UNTRACED | SIGCHLD, (void *) (intptr_t) getpid());
+	return clone(teardown_child, stack + sizeof stack, CLONE_VM | CLONE_UNTRACED | SIGCHLD, (void *) (intptr_t) getpid()) > 0;
 }
 
 int main(int argc, char *argv[])
@@ -210,9 +224,11 @@ int main(int argc, char *argv[])
 	std::cerr << "Time: " << secs << " s Memory: " << rss_kb() << " kbytes" << std::endl;
 	/* Everything is printed.  Tearing down the context, the lanes, the pinned pool and the HIP runtime in order costs
 	 * 0.13 s (tools/e2e_threads.py) and gives nothing back that the kernel driver does not reclaim at exit anyway, so
-	 * leave without it; NTSM_CLEAN_EXIT=1 runs the destructors (leak checks). */
+	 * leave without it; NTSM_CLEAN_EXIT=1 runs the destructors (leak checks).  The kernel's own teardown stays inside
+	 * this process's exit unless NTSM_FAST_EXIT=1 asks for the hand-over above (NTSM_SYNC_EXIT=1 overrides it). */
 	if (!getenv("NTSM_CLEAN_EXIT")) {
-		if (!getenv("NTSM_SYNC_EXIT")) hand_over_teardown();
+		const char *fast = getenv("NTSM_FAST_EXIT");
+		if (fast && fast[0] == '1' && !getenv("NTSM_SYNC_EXIT")) (void) hand_over_teardown();
 		std::cout.flush();
 		std::cerr.flush();
 		fflush(nullptr);

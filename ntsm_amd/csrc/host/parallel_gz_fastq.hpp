@@ -86,9 +86,14 @@ public:
 	}
 
 private:
-	struct Link { bool done = false, ok = false; std::string tail; };
+	/* end: the piece committed what it parsed but the parallel phase ends behind it (its tail is too long to carry on) */
+	struct Link { bool done = false, ok = false, end = false; std::string tail; };
 	static constexpr uint64_t kNone = ~0ull;
-	static constexpr size_t kMaxTail = 256u << 20;     /* a bridge longer than this (one read of > 128 Mb?) goes to the sequential reader */
+	/* a bridge longer than this (one read of > 128 Mb?) goes to the sequential reader; tests shrink it (set_max_tail) */
+	static std::atomic<size_t> &max_tail() { static std::atomic<size_t> v { 256u << 20 }; return v; }
+public:
+	static void set_max_tail(size_t bytes) { max_tail().store(bytes ? bytes : (size_t) 256u << 20); }
+private:
 
 	/* first record start in [p, e): a line start where a strict record parses and is followed by '@' (or ends the piece exactly) */
 	static uint64_t find_start(const char *p, const char *e, bool at_line_start)
@@ -117,21 +122,26 @@ private:
 		if (b == 0) { tail->clear(); return true; }
 		std::unique_lock<std::mutex> lk(m_mu);
 		m_cv.wait(lk, [&]() { return m_link[b - 1].done; });
-		if (!m_link[b - 1].ok) return false;
+		if (!m_link[b - 1].ok || m_link[b - 1].end) return false;
 		*tail = m_link[b - 1].tail;
 		return true;
 	}
-	void publish(uint64_t b, bool ok, std::string tail, std::unique_ptr<GzStream::Piece> piece)
+	/* end_here (with ok): piece b is committed up to its tail, and the phase ends there -- run() hands the tail and the later
+	 * pieces back to the stream exactly as after a failed link b -> b+1 */
+	void publish(uint64_t b, bool ok, std::string tail, std::unique_ptr<GzStream::Piece> piece, bool end_here = false)
 	{
 		{
 			std::lock_guard<std::mutex> lk(m_mu);
 			Link &l = m_link[b];
 			l.ok = ok;
+			l.end = end_here;
 			l.tail = std::move(tail);
 			l.done = true;
 			if (!ok) {
 				if (b < m_failSeq) m_failSeq = b;
 				m_kept[b] = std::move(piece);                      /* goes back to the stream */
+			} else if (end_here && b + 1 < m_failSeq) {
+				m_failSeq = b + 1;
 			}
 		}
 		m_cv.notify_all();
@@ -206,6 +216,7 @@ private:
 			}
 			if (alive && !linked) { alive = link_now(); linked = true; }
 			std::string tail;
+			bool end_here = false;
 			if (alive) {
 				if (first == kNone) {                               /* nothing parsed here: the previous tail + the whole piece */
 					tail = std::move(prev_tail);
@@ -213,7 +224,10 @@ private:
 				} else {
 					tail.assign(p, (size_t) (e - p));
 				}
-				if (tail.size() > kMaxTail) alive = false;
+				/* Too long to carry on.  The link INTO this piece held and records of it may have left with a flush already, so
+				 * the piece cannot go back whole (the sequential reader would count them a second time): it commits what it
+				 * parsed, and the phase ends at [p, e) like after a failed next link. */
+				if (tail.size() > max_tail().load(std::memory_order_relaxed)) end_here = true;
 			}
 			if (!alive) {
 				s.discard();
@@ -222,7 +236,8 @@ private:
 			}
 			s.flush();
 			n_records += n_here;
-			publish(b, true, std::move(tail), std::move(pc));
+			publish(b, true, std::move(tail), std::move(pc), end_here);
+			if (end_here) break;
 		}
 		m_records += n_records;
 	}

@@ -1172,7 +1172,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 				 * The cap only makes sense where a bigger set has somewhere else to go: k = 13, 14 have no 14-mer minimizers and a
 				 * context forced to one level (ntsm_set_kernel 2) must not fall back on a saturated 3 MiB filter -- those keep the
 				 * 2^e / 3 * 2^(e-2) ladder at >= 12 bits per key computed above (up to 64 MiB). */
-				const bool has_two_level_form = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 2;
+				const bool has_two_level_form = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 2 && c->kernel_variant != 3;   /* 3 (tabulated, make tab) is forced to one level too */
 				const uint64_t kib_want = std::max<uint64_t>(1, (27ull * n / 16 + 1023) / 1024);   /* 13.5 bits = 27/16 bytes per key */
 				if (has_two_level_form || kib_want <= 3072) {
 					const uint64_t kib = std::min<uint64_t>(3072, kib_want);

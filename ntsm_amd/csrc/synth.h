@@ -101,6 +101,36 @@ NTSM_HD unsigned char ntsm_synth_short_byte(const ntsm_synth_short *p, const uns
 	return ntsm_synth_letter(base);
 }
 
+/* Quality character of base j of short read r under quality model `model` (FASTQ text only: the count path never sees it).
+ *   0  constant 'I' (rounds 1-4; compresses 6:1 and is a copy of a copy ... of one line under DEFLATE)
+ *   1  "Illumina-like", 8-level binned (the instrument's Q-score binning: Phred 2, 6, 15, 22, 27, 33, 37, 40 = # ' 0 7 < B F I).
+ *      A read draws a level (one read in eight is a poor one) and a decay strength; the expected score falls with the square
+ *      of the position (late cycles are worse); every base draws its own deviation (mostly 0, sometimes -2 / -5 / -10 / -20,
+ *      rarely the floor) and a deviation is held over the next base with probability 1/2, so low scores come in short runs
+ *      as they do on an instrument; the result is rounded down to its bin.  All eight characters occur, the text compresses
+ *      about 3.5 : 1 under gzip -6 like real binned short-read FASTQ (constant 'I': 6 : 1), and a DEFLATE decoder meets literals
+ *      and short matches on the quality lines instead of one 150-byte copy per record.
+ *   2  the same without binning (Phred 2..41, ~39 distinct characters, 4.4 bits per score: 2.6 : 1 -- older instruments).
+ * Counter-based like the bases: a pure function of (seed, r, j). */
+NTSM_HD unsigned char ntsm_synth_qual_char(uint64_t seed, unsigned model, uint64_t r, uint32_t j, uint32_t read_len)
+{
+	if (model == 0) return 'I';
+	const uint64_t hr = ntsm_synth_rnd(seed, 10, r);
+	const int level = 41 - (((hr & 7) == 0) ? 6 + (int) ((hr >> 3) & 7) : 0);                           /* poor reads 28..35 */
+	const uint32_t decay = 4 + (uint32_t) ((hr >> 8) & 15);                                              /* 4..19 Phred lost by the last cycle */
+	const uint64_t jj = (uint64_t) j * j;
+	const int mean = level - (int) ((decay * jj) / ((uint64_t) read_len * read_len));
+	/* deviation of base j; with probability 1/2 the deviation of base j-1 is held instead (runs) */
+	uint64_t hb = ntsm_synth_rnd(seed, 9, r * 0x100000001B3ULL + j);
+	if (j > 0 && (hb >> 63)) hb = ntsm_synth_rnd(seed, 9, r * 0x100000001B3ULL + j - 1);
+	const unsigned t = (unsigned) (hb & 0xFF);
+	int q = mean - (t < 200 ? 0 : t < 224 ? 2 : t < 240 ? 5 : t < 249 ? 10 : t < 254 ? 20 : 64);
+	if (q < 2) q = 2;
+	if (q > 41) q = 41;
+	if (model == 1) q = q >= 40 ? 40 : q >= 37 ? 37 : q >= 33 ? 33 : q >= 27 ? 27 : q >= 22 ? 22 : q >= 15 ? 15 : q >= 6 ? 6 : 2;
+	return (unsigned char) (33 + q);
+}
+
 /* Length of long read r from a 257-entry quantile table (host-built, monotone). */
 NTSM_HD uint32_t ntsm_synth_long_len(uint64_t seed, const uint32_t *qtable, uint64_t r)
 {

@@ -248,36 +248,52 @@ void ntsm_synth_long_fill_host(const ntsm_synth_long *p, const uint8_t *windows,
 	}
 }
 
-int ntsm_synth_short_write_fastq(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
-		uint64_t n_reads, const char *path)
+static void short_record(const ntsm_synth_short *p, const uint8_t *windows, unsigned qual_model, uint64_t r, std::vector<uint8_t> &seq,
+		std::string &buf)
+{
+	const uint32_t L = p->read_len;
+	ntsm_synth_short_fill_host(p, windows, r * ((uint64_t) L + 1), L, seq.data());
+	buf += "@r";
+	buf += std::to_string(r);
+	buf += '\n';
+	buf.append((const char *) seq.data(), L);
+	buf += "\n+\n";
+	if (qual_model == 0) buf.append(L, 'I');
+	else for (uint32_t j = 0; j < L; ++j) buf += (char) ntsm_synth_qual_char(p->seed, qual_model, r, j, L);
+	buf += '\n';
+}
+
+int ntsm_synth_short_write_fastq_q(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
+		uint64_t n_reads, const char *path, unsigned qual_model)
 {
 	Out out;
 	if (!out.open(path)) return -2;
-	const uint64_t stride = (uint64_t) p->read_len + 1;
-	std::vector<uint8_t> seq(stride);
-	std::string rec, qual(p->read_len, 'I');
+	std::vector<uint8_t> seq((size_t) p->read_len + 1);
+	std::string rec;
 	for (uint64_t r = r0; r < r0 + n_reads; ++r) {
-		ntsm_synth_short_fill_host(p, windows, r * stride, p->read_len, seq.data());
-		rec = "@r" + std::to_string(r) + "\n";
-		rec.append((const char *) seq.data(), p->read_len);
-		rec += "\n+\n";
-		rec += qual;
-		rec += "\n";
+		rec.clear();
+		short_record(p, windows, qual_model, r, seq, rec);
 		out.write(rec.data(), rec.size());
 	}
 	out.close();
 	return 0;
 }
 
-/* The same bytes as ntsm_synth_short_write_fastq (plain output only), written by n_threads threads: the record of read
+int ntsm_synth_short_write_fastq(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
+		uint64_t n_reads, const char *path)
+{
+	return ntsm_synth_short_write_fastq_q(p, windows, r0, n_reads, path, 0);
+}
+
+/* The same bytes as ntsm_synth_short_write_fastq_q (plain output only), written by n_threads threads: the record of read
  * r is 2 + digits(r) + 1 + L + 3 + L + 1 bytes, so every thread knows where its slice of reads starts in the file and
  * writes it there with pwrite().  For the multi-gigabyte inputs of the end-to-end CLI measurements. */
-int ntsm_synth_short_write_fastq_mt(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
-		uint64_t n_reads, const char *path, unsigned n_threads)
+int ntsm_synth_short_write_fastq_mt_q(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
+		uint64_t n_reads, const char *path, unsigned n_threads, unsigned qual_model)
 {
 	size_t plen = strlen(path);
 	if (n_threads <= 1 || (plen > 3 && !strcmp(path + plen - 3, ".gz")))
-		return ntsm_synth_short_write_fastq(p, windows, r0, n_reads, path);
+		return ntsm_synth_short_write_fastq_q(p, windows, r0, n_reads, path, qual_model);
 	auto digits_sum = [](uint64_t a, uint64_t b) {             /* sum of the decimal lengths of a .. b-1 */
 		uint64_t s = 0, lo = 1, d = 1;
 		for (; d <= 20; ++d) {
@@ -300,9 +316,8 @@ int ntsm_synth_short_write_fastq_mt(const ntsm_synth_short *p, const uint8_t *wi
 		pool.emplace_back([&, t]() {
 			const uint64_t a = r0 + n_reads * t / n_threads, b = r0 + n_reads * (t + 1) / n_threads;
 			uint64_t off = (a - r0) * fixed + digits_sum(r0, a);
-			const uint64_t stride = L + 1;
-			std::vector<uint8_t> seq(stride);
-			std::string buf, qual(L, 'I');
+			std::vector<uint8_t> seq(L + 1);
+			std::string buf;
 			buf.reserve((8u << 20) + 2 * fixed);
 			auto flush = [&]() {
 				size_t done = 0;
@@ -315,14 +330,7 @@ int ntsm_synth_short_write_fastq_mt(const ntsm_synth_short *p, const uint8_t *wi
 				buf.clear();
 			};
 			for (uint64_t r = a; r < b && rcs[t] == 0; ++r) {
-				ntsm_synth_short_fill_host(p, windows, r * stride, L, seq.data());
-				buf += "@r";
-				buf += std::to_string(r);
-				buf += '\n';
-				buf.append((const char *) seq.data(), L);
-				buf += "\n+\n";
-				buf += qual;
-				buf += '\n';
+				short_record(p, windows, qual_model, r, seq, buf);
 				if (buf.size() >= (8u << 20)) flush();
 			}
 			if (rcs[t] == 0) flush();
@@ -331,6 +339,12 @@ int ntsm_synth_short_write_fastq_mt(const ntsm_synth_short *p, const uint8_t *wi
 	close(fd);
 	for (int rc : rcs) if (rc) return rc;
 	return 0;
+}
+
+int ntsm_synth_short_write_fastq_mt(const ntsm_synth_short *p, const uint8_t *windows, uint64_t r0,
+		uint64_t n_reads, const char *path, unsigned n_threads)
+{
+	return ntsm_synth_short_write_fastq_mt_q(p, windows, r0, n_reads, path, n_threads, 0);
 }
 
 int ntsm_synth_long_write_fastq(const ntsm_synth_long *p, const uint8_t *windows, const uint32_t *q,

@@ -1310,25 +1310,51 @@ def test_cli_clean_exit_runs_the_destructors(nt):
         assert a.stdout == b.stdout and len(a.stdout) > 1000 and _summary(a.stderr) == _summary(b.stderr)
 
 
+def _ntsm_procs(zombies):
+    out = subprocess.run(["ps", "-eo", "pid,stat,comm"], stdout=subprocess.PIPE).stdout.decode().split("\n")
+    return [l for l in out if "ntsmCount" in l and ((" Z" in l) == zombies)]
+
+
+def test_cli_exit_is_synchronous_by_default(nt, tmp_path):
+    """The reference returns from main (src/ntSeqMatchCount.cpp:182-185): when the caller's wait() returns the process is
+    gone, with its HBM, pinned memory and /dev/kfd handles.  Same here by default (round 4 handed the kernel's teardown of
+    the HIP process to a clone(CLONE_VM) child; that is opt-in now, see the next test): right after every run -- a good
+    one, an armed one, a failing one -- there is no live ntsmCount process and no zombie, without waiting."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    inp = os.path.join(G, "inputs")
+    env = {k: v for k, v in os.environ.items() if k not in ("NTSM_FAST_EXIT", "NTSM_SYNC_EXIT", "NTSM_CLEAN_EXIT")}
+    ref = subprocess.run([exe, "-s", "sites200.fa", "-t", "4", "reads2k.fq", "reads600.fq.gz"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         env=dict(env, NTSM_SYNC_EXIT="1"))
+    assert ref.returncode == 0 and len(ref.stdout) > 1000
+    before = set(_ntsm_procs(zombies=True))                 # somebody else's leftovers are not this test's business
+    for args in (["-s", "sites200.fa", "-t", "4", "reads2k.fq", "reads600.fq.gz"], ["-s", "sites200.fa", "-m", "1", "reads2k.fq"],
+                 ["-s", "no_such_sites.fa", "reads2k.fq"]):
+        for _ in range(3):
+            p = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert not _ntsm_procs(zombies=False) and not set(_ntsm_procs(zombies=True)) - before, (args, _ntsm_procs(False), _ntsm_procs(True))
+            if args[1] == "sites200.fa" and "-t" in args:
+                assert p.returncode == 0 and p.stdout == ref.stdout and _summary(p.stderr) == _summary(ref.stderr)
+
+
 def test_cli_hands_its_teardown_to_a_child(nt, tmp_path):
-    """After the last line is printed the CLI starts a clone(CLONE_VM) child that outlives it by the kernel's teardown of
-    the HIP process (ntsm_count_main.cpp: hand_over_teardown) and leaves.  Same bytes and exit status as with the teardown
-    inside exit(2) (NTSM_SYNC_EXIT=1); the child closes its copies of stdout / stderr at once (a reader of the pipes sees the
-    end when the CLI goes, not 0.15 s later) and is gone -- at most a zombie waiting for init -- a moment afterwards; a run
-    that fails (no such input) takes the ordinary exit and leaves nothing behind either."""
+    """NTSM_FAST_EXIT=1 (opt-in): after the last line is printed the CLI starts a clone(CLONE_VM) child that outlives it by
+    the kernel's teardown of the HIP process (ntsm_count_main.cpp: hand_over_teardown) and leaves.  Same bytes and exit
+    status as the default; the child closes its copies of stdout / stderr at once (a reader of the pipes sees the end when
+    the CLI goes, not 0.15 s later) and is gone -- at most a zombie waiting for init -- a moment afterwards; NTSM_SYNC_EXIT=1
+    overrides it; a run that fails (no such input) takes the ordinary exit and leaves nothing behind either."""
     import time
     exe = os.path.join(ROOT, "build", "ntsmCount")
     inp = os.path.join(G, "inputs")
     args = ["-s", "sites200.fa", "-t", "4", "reads2k.fq", "reads600.fq.gz"]
-    a = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, NTSM_SYNC_EXIT="1"))
+    fast = dict(os.environ, NTSM_FAST_EXIT="1")
+    fast.pop("NTSM_SYNC_EXIT", None)
+    a = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == 0 and len(a.stdout) > 1000
-    def live_ntsm():
-        out = subprocess.run(["ps", "-eo", "pid,stat,comm"], stdout=subprocess.PIPE).stdout.decode().split("\n")
-        return [l for l in out if "ntsmCount" in l and " Z" not in l]
+    live_ntsm = lambda: _ntsm_procs(zombies=False)
     walls = []
     for _ in range(3):
         t0 = time.perf_counter()
-        b = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=fast)
         walls.append(time.perf_counter() - t0)
         assert b.returncode == 0 and b.stdout == a.stdout and _summary(b.stderr) == _summary(a.stderr)
         own = [l for l in b.stderr.decode().split("\n") if l.startswith("Time: ")]
@@ -1338,7 +1364,9 @@ def test_cli_hands_its_teardown_to_a_child(nt, tmp_path):
     while live_ntsm() and time.time() < deadline:
         time.sleep(0.05)
     assert not live_ntsm()
-    subprocess.run([exe, "-s", "no_such_sites.fa", "reads2k.fq"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    c = subprocess.run([exe] + args, cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(fast, NTSM_SYNC_EXIT="1"))
+    assert c.returncode == 0 and c.stdout == a.stdout and not live_ntsm()
+    subprocess.run([exe, "-s", "no_such_sites.fa", "reads2k.fq"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=fast)
     time.sleep(0.3)
     assert not live_ntsm()
 
@@ -1372,12 +1400,16 @@ def test_bench_contract_line(nt):
     scaled: value = bases / time, frac = achieved / peak."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2e6", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000",
                         "--long-reads", "2e4", "--stress-sites", "2e4", "--stress-reads", "1e6", "--n10-full-sites", "2e4", "--n10-full-reads", "1e6",
-                        "--e2e-reads", "2e5", "--e2e-threads", "4"],
+                        "--e2e-reads", "2e5", "--e2e-gz-single-reads", "5e4", "--e2e-threads", "4"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()[-1500:]
     lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert a.stress_reads == 1e9 and a.n10_full_reads == 1e9 and a.reads == 1e9          # configs[1] and configs[4] at BASELINE.json's stated size by default
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -1391,8 +1423,20 @@ def test_bench_contract_line(nt):
     assert d["check"]["equals_generic_kernel_sum_of_pieces_below_2GiB"] is True
     # the secondary configurations ride on the same line, each with its own check (configs[2], configs[4], CLI)
     o = d["other_configs"]
-    assert set(o) == {"long", "stress", "n10_full", "e2e_cli", "e2e_cli_gz"} and not any("error" in v for v in o.values()), o
+    assert set(o) == {"long", "stress", "n10_full", "e2e_cli", "e2e_cli_gz", "e2e_cli_gz_single"} and not any("error" in v for v in o.values()), o
     assert o["e2e_cli_gz"]["check"]["counts_txt_equals_plain_fastq_run"] and o["e2e_cli_gz"]["wall_s"] > 0
+    # the CLI legs: realistic quality lines, an ordinary single-threaded gzip stream beside the pigz-style one, both exit
+    # modes reported (wall_s = the default, synchronous one), the host's CPU grant stated
+    g1 = o["e2e_cli_gz_single"]
+    assert g1["check"]["counts_txt_equals_plain_sample_run"] and g1["reads"] == 50000 and "one thread" in g1["writer"]
+    assert 2.5 < g1["compression_ratio"] < 4.5 and 2.5 < o["e2e_cli_gz"]["compression_ratio"] < 4.5      # constant 'I' gave 6:1
+    for leg in (o["e2e_cli"], o["e2e_cli_gz"], g1):
+        assert "8-level" in leg["quality_lines"] and leg["wall_s"] > 0 and leg["wall_s_fast_exit"] > 0 and leg["text_GB_per_s"] > 0
+        assert leg["exit_mode_of_wall_s"].startswith("default: synchronous")
+        assert leg["host"]["cpus_online"] >= 1 and "cgroup_cpu_max" in leg["host"] and "cgroup_cpus" in leg["host"]
+    fr = d["roofline"]["frac_range"]
+    assert len(fr) == 2 and fr[0] <= fr[1] and set(fr) == {o["n10_full"]["roofline_frac"], r["frac"]}
+    assert o["stress"]["reads"] == o["stress"]["reads_asked"] == 1000000
     assert o["n10_full"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["n10_full"]["site_kmers"] == 2 * 13 * 20000
     assert o["long"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["long"]["gbases_per_s"] > 0 and 0 < o["long"]["roofline_frac"] < 1
     assert o["long"]["m10"]["early_stop"] in (True, False) and o["long"]["m10"]["stop_read"] <= o["long"]["reads"]

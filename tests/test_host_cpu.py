@@ -696,6 +696,65 @@ def test_parallel_gzip_ingest_under_tsan(nt, tmp_path):
             assert len(outs) == 1 and b"reads=12000 " in outs.pop(), outs
 
 
+def test_parallel_gzip_ingest_long_unparsable_rest_is_not_counted_twice(nt, tmp_path):
+    """ADVICE round 4 (parallel_gz_fastq.hpp): a piece whose unparsed rest is too long to carry into the next link used to go
+    back to the stream WHOLE -- after its link had held and a full sink had already flushed records of it, which the sequential
+    reader then parsed a second time.  Now it commits what it parsed and the phase ends at the rest.  Provoked with a small
+    limit (debug hook; the default is 256 MiB), sinks much smaller than a piece, and one record wrapped over 3,000 lines in the
+    middle of strict records: the same multiset of reads as the sequential reader, for several piece sizes."""
+    import collections
+    from ntsm_amd.capi import debug_gz_max_tail, flatten_file, flatten_file_parallel_gz, gunzip_parallel_chunk
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
+    fq = str(tmp_path / "t.fq")
+    s.write_fastq(fq, 0, 12000)
+    lines = open(fq, "rb").read().split(b"\n")
+    long_seq = (b"ACGTTGCAAGCTTAGC" * 4 + b"\n") * 3000                       # one record, sequence wrapped over 3,000 lines (195 KB)
+    long_rec = b"@wrapped\n" + long_seq + b"+\n" + (b"I" * 64 + b"\n") * 3000
+    data = b"\n".join(lines[:20000]) + b"\n" + long_rec + b"\n".join(lines[20000:])
+    p = str(tmp_path / "wrapped.gz")
+    open(p, "wb").write(_gz_member(data, 6))
+    ref_b, ref_e, _ = flatten_file(p)
+    ref = collections.Counter(_reads_of(ref_b, ref_e))
+    assert len(ref_e) == 12001
+    try:
+        debug_gz_max_tail(5000)
+        for chunk, dec, par, sink in ((20000, 4, 4, 2000), (60000, 3, 2, 3000), (8000, 2, 3, 1500)):
+            gunzip_parallel_chunk(chunk)
+            b, e, info = flatten_file_parallel_gz(p, dec, par, sink)
+            got = collections.Counter(_reads_of(b, e))
+            assert got == ref and len(e) == len(ref_e), (chunk, dec, par, sink, len(e), len(ref_e), info)
+            assert 0 < info["parallel_records"] < len(ref_e)
+    finally:
+        debug_gz_max_tail(0)
+        gunzip_parallel_chunk(0)
+
+
+def test_early_ingest_allocation_failure_is_an_error_not_a_shorter_run(nt, tmp_path):
+    """ADVICE round 4 (early_ingest.cpp): a chunk that cannot be allocated used to look like an abandoned run -- the sink dropped
+    its records and the CLI printed counts of fewer reads with exit status 0.  Now the ingest records the failure
+    (EarlyIngest::failed), the host hook answers -3, and FingerPrint::drainEarly turns it into exit(1) with a message (the
+    GPU-side test drives the CLI).  Failing the 1st, 3rd and 9th allocation, plain and gzip input."""
+    from ntsm_amd.capi import NtsmError, debug_early_alloc_fail, early_ingest
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
+    fq = str(tmp_path / "t.fq")
+    s.write_fastq(fq, 0, 40000)
+    gz = str(tmp_path / "t.fq.gz")
+    open(gz, "wb").write(_gz_member(open(fq, "rb").read(), 4))
+    ok = early_ingest(fq, 4, 3, 1 << 20, 60_000, 64, 2)
+    assert ok is not None and ok[1] == 40000
+    try:
+        for path in (fq, gz):
+            for nth in (1, 3, 9):
+                debug_early_alloc_fail(nth)
+                with pytest.raises(NtsmError, match="-3"):
+                    early_ingest(path, 4, 3, 1 << 20, 60_000, 64, 2)
+                debug_early_alloc_fail(0)
+                again = early_ingest(path, 4, 3, 1 << 20, 60_000, 64, 2)     # and the next run is whole again
+                assert again is not None and again[1] == 40000 and again[2] == ok[2]
+    finally:
+        debug_early_alloc_fail(0)
+
+
 def test_early_ingest_packs_the_same_reads(nt, tmp_path):
     """early_ingest.hpp: the first input file parsed into packed chunks in ordinary memory while the sites load.  The chunks
     of a plain FASTQ and of the same reads as .gz hold the same reads as the sequential reader delivers: same number of reads

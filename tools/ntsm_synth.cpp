@@ -2,7 +2,7 @@
  * tools/ntsm_synth.cpp -- command-line front end of the synthetic workload generator.
  *   ntsm_synth sites --seed S --n-sites N [--k 19] --out sites.fa[.gz]
  *   ntsm_synth reads --seed S --sites-seed S0 --n-sites N [--k 19] [--len 150] [--r0 0] --n-reads R
- *                    [--p-embed 0.1] [--p-sub 0.01] [--p-n 0.0005] --out reads.fq[.gz]
+ *                    [--p-embed 0.1] [--p-sub 0.01] [--p-n 0.0005] [--qual-model 0|1] --out reads.fq[.gz]
  *   ntsm_synth long  --seed S --sites-seed S0 --n-sites N [--spacing 20000] [--mu 9.6] [--sigma 0.6]
  *                    [--lo 200] [--hi 200000] [--p-sub 0.05] [--r0 0] --n-reads R --out reads.fq[.gz]
  */
@@ -41,7 +41,7 @@ int main(int argc, char **argv)
 		ntsm_synth_short p;
 		ntsm_synth_short_params(&p, seed, (uint32_t) U("--len", "150"), n_sites, D("--p-embed", "0.1"),
 				D("--p-sub", "0.01"), D("--p-n", "0.0005"));
-		return ntsm_synth_short_write_fastq(&p, win.data(), r0, n_reads, out.c_str()) ? 1 : 0;
+		return ntsm_synth_short_write_fastq_q(&p, win.data(), r0, n_reads, out.c_str(), (unsigned) U("--qual-model", "0")) ? 1 : 0;
 	}
 	if (mode == "long") {
 		ntsm_synth_long p;
