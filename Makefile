@@ -1,5 +1,5 @@
 # Top-level build.  `make all` = everything __graft_entry__.build() needs:
-#   ntsm_amd/libntsm_hip.so   HIP kernels + C ABI (include/ntsm_hip.h), gfx950
+#   ntsm_amd/libntsm_hip.so   HIP kernels + C ABI (include/ntsm_hip.h), gfx950: csrc/kernels_*.hip + tables / runtime / rccl_bind / capi .cpp
 #   ntsm_amd/libntsm_synth.so synthetic workload generator (host + device fills)
 #   build/ntsmCount           host CLI (C++), links libntsm_hip.so
 #   build/ntsm_synth          generator CLI
@@ -29,14 +29,26 @@ build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/early_ingest.cpp $(H
 	$(CXX) $(CXXFLAGS) -o $@ $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/early_ingest.cpp $(HOST)/ntsm_count_main.cpp \
 	    -Lntsm_amd -lntsm_hip -lz -pthread -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
-ntsm_amd/libntsm_hip.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_device.h include/ntsm_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ntsm_hip.hip -ldl
+# libntsm_hip.so = two device translation units (the kernels + their launchers) and four host-only ones
+HIPLIB_DEV  := $(CSRC)/kernels_generic.hip $(CSRC)/kernels_mz.hip
+HIPLIB_HOST := $(CSRC)/tables.cpp $(CSRC)/runtime.cpp $(CSRC)/rccl_bind.cpp $(CSRC)/capi.cpp
+HIPLIB_HDR  := $(CSRC)/ntsm_internal.h $(CSRC)/kernels_common.h $(CSRC)/ntsm_hooks.h $(CSRC)/ntsm_device.h include/ntsm_hip.h
+HIPLIB_TAB  := $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_tab_launch.inc $(CSRC)/ntsm_tab_runtime.inc $(CSRC)/ntsm_tab_tables.inc
+# $(call hiplib,output,extra flags,object dir): every source to its own object (in parallel under -j), then one link
+define hiplib
+	@mkdir -p $(3)
+	for f in $(HIPLIB_DEV) $(HIPLIB_HOST); do $(HIPCC) $(HIPFLAGS) -fvisibility=hidden $(2) -c $$f -o $(3)/$$(basename $$f).o & done; wait
+	$(HIPCC) $(HIPFLAGS) -shared -o $(1) $(foreach f,$(HIPLIB_DEV) $(HIPLIB_HOST),$(3)/$(notdir $(f)).o) -ldl
+endef
+
+ntsm_amd/libntsm_hip.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR)
+	$(call hiplib,$@,,build/obj)
 
 # the same ABI with the tabulated k = 19 kernel compiled in (ntsm_set_kernel(ctx, 3)): a measured negative result kept
 # buildable and tested (tests/test_gpu_parity.py::test_tabulated_kernel_paths loads it through NTSM_HIP_LIB), not shipped
 tab: ntsm_amd/libntsm_hip_tab.so
-ntsm_amd/libntsm_hip_tab.so: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h
-	$(HIPCC) $(HIPFLAGS) -DNTSM_WITH_TAB -shared -o $@ $(CSRC)/ntsm_hip.hip -ldl
+ntsm_amd/libntsm_hip_tab.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR) $(HIPLIB_TAB)
+	$(call hiplib,$@,-DNTSM_WITH_TAB,build/obj_tab)
 
 # ntsmEval all-pairs scoring: own library, own CLI
 ntsm_amd/libntsm_eval_hip.so: $(CSRC)/ntsm_eval.hip include/ntsm_eval_hip.h
@@ -47,9 +59,14 @@ build/ntsmEval: $(HOST)/ntsm_eval_main.cpp include/ntsm_eval_hip.h ntsm_amd/libn
 	$(CXX) $(CXXFLAGS) -ffp-contract=off -o $@ $(HOST)/ntsm_eval_main.cpp -Lntsm_amd -lntsm_eval_hip \
 	    -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
-# ablation builds of the tabulated kernel for tools/ab_libs.sh (never shipped: wrong counts by construction)
-ablation: $(CSRC)/ntsm_hip.hip $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_device.h include/ntsm_hip.h
-	for a in $(or $(ABL),1 2 4 5 7 8); do $(HIPCC) $(HIPFLAGS) -DNTSM_WITH_TAB -DNTSM_ABLATION -DNTSM_TAB_ABL=$$a -shared -o ntsm_amd/libntsm_hip_abl$$a.so $(CSRC)/ntsm_hip.hip -ldl & done; wait
+# ablation builds (never shipped: wrong counts by construction).  `make ablation`: the default kernels with the switches of
+# ntsm_ablation.inc (NTSM_DEBUG_KERNEL ...) -> ntsm_amd/libntsm_hip_abl.so; `make ablation ABL="1 2 4"`: the tabulated
+# kernel's compile-time ablations as well -> ntsm_amd/libntsm_hip_abl<N>.so (tools/ablate.sh drives both)
+ablation: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR) $(HIPLIB_TAB) $(CSRC)/ntsm_ablation.inc
+	$(call hiplib,ntsm_amd/libntsm_hip_abl.so,-DNTSM_ABLATION $(ABLFLAGS),build/obj_abl)
+	for a in $(ABL); do $(MAKE) --no-print-directory abl_tab A=$$a; done
+abl_tab:
+	$(call hiplib,ntsm_amd/libntsm_hip_abl$(A).so,-DNTSM_WITH_TAB -DNTSM_ABLATION -DNTSM_TAB_ABL=$(A),build/obj_abl$(A))
 
 ntsm_amd/libntsm_synth.so: $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp -lz
@@ -68,4 +85,4 @@ build/gather_bench: tools/gather_bench.hip
 clean:
 	rm -rf build ntsm_amd/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle_all clean ablation tab
+.PHONY: all oracle_all clean ablation abl_tab tab

@@ -480,7 +480,19 @@ def _phase_seconds(phases, key, exclude=None):
     return None
 
 
-def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
+def e2e_start_single_stream(synth, args, tmp):
+    """The ordinary single-threaded `gzip -6` of the sample takes about a minute of one CPU (1.26 GB of text at 20-25 MB/s): it
+    is started before the GPU-bound legs (long / stress / n10_full leave the host idle) and collected by config_e2e."""
+    n_single = max(1000, min(int(args.e2e_reads), int(args.e2e_gz_single_reads)))
+    sample = os.path.join(tmp, "e2e_sample.fq")
+    host = host_info()
+    synth.write_fastq(sample, 0, n_single, threads=max(1, min(32, int(host["cgroup_cpus"] or 0) or (os.cpu_count() or 2) - 1)), qual_model=int(args.e2e_qual_model))
+    t0 = time.perf_counter()
+    writer, job = _gzip_single_stream(sample, sample + ".gz")
+    return {"n": n_single, "sample": sample, "sample_gz": sample + ".gz", "writer": writer, "job": job, "t0": t0}
+
+
+def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp, single=None):
     """File -> counts.txt through the CLI (build/ntsmCount -t N), the whole process timed, on a generated FASTQ whose quality
     lines follow the Illumina-like 8-level model of synth.h (position-dependent decay, low scores in runs; gzip -6 ratio about
     3.5:1 -- rounds 1-4 wrote 150 x 'I', 6:1 and one long copy per record for a DEFLATE decoder):
@@ -527,20 +539,16 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
            "phases": phases, "fastq_gen_s": t_gen, "counts_sha256": sha_cli, "check": {"counts_txt_equals_resident_path": True}}
     out.update(exits)
     gz_out = single_out = None
-    sample = os.path.join(tmp, "e2e_sample.fq")
-    sample_gz = sample + ".gz"
     gz = os.path.join(tmp, "e2e.fq.gz")
+    if single is None:
+        single = e2e_start_single_stream(synth, args, tmp)
+    sample, sample_gz, n_single, writer, job, t0s = single["sample"], single["sample_gz"], single["n"], single["writer"], single["job"], single["t0"]
     try:
-        # the single-stream sample is compressed by ONE thread beside the pigz-style writer (neither is timed)
-        n_single = max(1000, min(n_reads, int(args.e2e_gz_single_reads)))
-        synth.write_fastq(sample, 0, n_single, threads=gen_threads, qual_model=qm)
-        t0s = time.perf_counter()
-        writer, job = _gzip_single_stream(sample, sample_gz)
         t0 = time.perf_counter()
         gz_size = pigz_like(fq, gz, threads=max(1, min(48, int(host["cgroup_cpus"] or 0) or (os.cpu_count() or 2) - 1)))
         t_gz = time.perf_counter() - t0
         os.unlink(fq)
-        job.wait()
+        job.wait()                                             # (started before the GPU legs; neither writer is timed)
         t_single = time.perf_counter() - t0s
         if getattr(job, "returncode", 0):
             raise RuntimeError("gzip -6 of the sample failed: %r" % job.returncode)
@@ -568,11 +576,24 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp):
         sb = n_single * READ_LEN
         early = any("early ingest" in l for l in phases)
         infl = None if early else _phase_seconds(phases, "inflate+parse+count")
+        # a file of this size is usually inflated and parsed entirely beside the start-up (early ingest): that phase's own clock
+        early_s = early_n = None
+        for l in phases:
+            if "early ingest" in l and " parsed " in l:
+                try:
+                    early_n = int(l.split(" parsed ")[1].split()[0])
+                    early_s = float(l.split(") in ")[1].split(" s")[0])
+                except (ValueError, IndexError):
+                    pass
         single_out = {"workload": "build/ntsmCount -t %d on the first %.3g reads as ONE ordinary single-threaded gzip stream (%.2f GB)" % (args.e2e_threads, n_single, s_gz_size / 1e9),
                       "writer": writer, "quality_lines": quality, "host": host, "compression_ratio": s_size / s_gz_size,
                       "reads": n_single, "file_bytes": s_gz_size, "text_bytes": s_size, "wall_s": wall, "gbases_per_s": sb / wall / 1e9,
                       "cli_reported_s": cli_s, "text_GB_per_s": s_size / wall / 1e9,
                       "inflate_parse_count_s": infl, "text_GB_per_s_inflate_parse_count": s_size / infl / 1e9 if infl else None,
+                      "early_ingest_records": early_n, "early_ingest_s": early_s,
+                      "text_GB_per_s_early_ingest": (s_size * early_n / n_single) / early_s / 1e9 if early_s and early_n else None,
+                      "note": "the pigz-style file of e2e_cli_gz is the same decoding problem at ten times the size: its only flush points are one per 64 MiB of "
+                              "text, so all but ~200 of its ~3,400 one-MiB chunks start in the middle of the stream exactly like every chunk of this file",
                       "phases": phases, "gzip_s": t_single, "counts_sha256": hashlib.sha256(ps.stdout).hexdigest(),
                       "check": {"counts_txt_equals_plain_sample_run": True}}
         single_out.update(exits)
@@ -814,6 +835,12 @@ def run_rank(args):
         which = [w for w in args.other_configs.split(",") if w and w != "none"] if world == 1 and not use_dist else []
         if which:
             other = {}
+            single = None
+            if "e2e" in which:
+                try:
+                    single = e2e_start_single_stream(synth, args, tmp)    # one CPU's worth of gzip -6 beside the GPU-bound legs
+                except Exception:
+                    single = None
             for name in which:
                 t0 = time.perf_counter()
                 try:
@@ -824,7 +851,7 @@ def run_rank(args):
                     elif name == "n10_full":
                         other["n10_full"] = config_n10_full(ntsm_amd, torch, dev, local, args, tmp)
                     elif name == "e2e":
-                        other["e2e_cli"], other["e2e_cli_gz"], other["e2e_cli_gz_single"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp)
+                        other["e2e_cli"], other["e2e_cli_gz"], other["e2e_cli_gz_single"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp, single)
                     else:
                         continue
                 except AssertionError:

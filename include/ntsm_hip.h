@@ -205,6 +205,17 @@ int ntsm_set_kernel(ntsm_ctx *ctx, int variant);
  * were queued for the look-up kernel (since creation or the last ntsm_reset), out[5] = 1 when the tables are the
  * two-level ones, out[6] = words of the minimizer Bloom, out[7] = distinct site minimizers (two-level tables). */
 int ntsm_debug_stats(ntsm_ctx *ctx, uint64_t out[8]);
+/* Fault injection for tests of the failure paths (compiled into every build, armed ONLY through this call -- the library
+ * reads no environment variable).  kind 1: device allocations, 2: host-to-device copies, 3: pinned host allocations.
+ * nth > 0: the nth call of that kind from now on (process-wide, any context) does not reach the HIP runtime and reports
+ * hipErrorOutOfMemory (allocations) / hipErrorUnknown (copies); only that one call fails.  nth = 0 disarms.  Returns the
+ * number of calls of that kind seen since the previous arming (so a test can first count the calls an operation makes and
+ * then fail each in turn), -1 for an unknown kind.  What a failure must look like to the caller: ntsm_create returns an
+ * error and leaves nothing allocated; a failed table rebuild (ntsm_set_kernel / ntsm_set_tuning) or a lost lane batch marks
+ * the context failed -- every later counting / merging / reporting call answers NTSM_ERR_STATE, ntsm_lane_close repeats the
+ * lane's first error -- so an incomplete count can never be printed (the reference: exit(1) with a message,
+ * src/FingerPrint.hpp:51-57, :493-499). */
+long long ntsm_debug_fail_after(int kind, long long nth);
 /* The HIP stream (hipStream_t) ntsm_count_resident launches on. */
 void *ntsm_stream(ntsm_ctx *ctx);
 

@@ -84,6 +84,7 @@ _sig(H, "ntsm_set_kernel", C.c_int, [C.c_void_p, C.c_int])
 _sig(H, "ntsm_set_armed_chunk", C.c_int, [C.c_void_p, C.c_uint64])
 _sig(H, "ntsm_stream", C.c_void_p, [C.c_void_p])
 _sig(H, "ntsm_debug_stats", C.c_int, [C.c_void_p, u64p])
+_sig(H, "ntsm_debug_fail_after", C.c_longlong, [C.c_int, C.c_longlong])
 _sig(H, "ntsm_hash64", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_hash64_inv", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_strerror", C.c_char_p, [C.c_int])
@@ -455,6 +456,15 @@ def allreduce(contexts):
     context's counts()/sync() report the job-wide result."""
     arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
     _chk(H.ntsm_allreduce(arr, len(contexts)), "ntsm_allreduce")
+
+
+FAULT_DEVICE_ALLOC, FAULT_H2D, FAULT_PINNED_ALLOC = 1, 2, 3
+
+
+def debug_fail_after(kind, nth):
+    """ntsm_debug_fail_after: the nth call of `kind` (FAULT_*) from now on fails; 0 disarms.  Returns the calls of that kind
+    seen since the previous arming."""
+    return int(H.ntsm_debug_fail_after(int(kind), int(nth)))
 
 
 def warmup(device=0, n_streams=0):

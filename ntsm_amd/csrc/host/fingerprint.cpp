@@ -10,6 +10,7 @@
 #include <sstream>
 #include <thread>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "early_ingest.hpp"
 #include "gz_stream.hpp"
@@ -34,15 +35,33 @@ static uint64_t threshold_from(double n_distinct, double cov)
 	return (uint64_t) x;
 }
 
-void Feeder::die(int rc, const char *what) const
+static std::mutex g_stderr;
+
+/* A run that cannot go on ends with ONE message and exit status 1 (the reference: `exit(1)` where it cannot open a file,
+ * src/FingerPrint.hpp:51-57).  The caller may be one of several feeder threads that all see the same failure (a lost lane
+ * batch marks the whole context failed): the first one reports, the others wait for it.  _exit, not exit: the other threads
+ * are inside the HIP runtime and nothing has been written to stdout yet (counts are printed only after everything is
+ * counted), so there is nothing to flush and no destructor worth racing them for. */
+[[noreturn]] static void fatal(const std::string &message)
 {
-	std::cerr << "ntsmCount: " << what << ": " << ntsm_strerror(rc);
-	if (rc == NTSM_ERR_HIP) std::cerr << " (hipError " << ntsm_last_hip_error() << ")";
-	std::cerr << std::endl;
-	exit(1);
+	static std::atomic<bool> dying { false };
+	if (dying.exchange(true)) for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+	{
+		std::lock_guard<std::mutex> lk(g_stderr);
+		std::cerr << message << std::endl;
+	}
+	fflush(nullptr);
+	_exit(1);
 }
 
-static std::mutex g_stderr;
+void Feeder::die(int rc, const char *what) const
+{
+	std::ostringstream m;
+	m << "ntsmCount: " << what << ": " << ntsm_strerror(rc);
+	if (rc == NTSM_ERR_HIP) m << " (hipError " << ntsm_last_hip_error() << ")";
+	fatal(m.str());
+}
+
 /* Staging slot of a producer lane (-t N): 8 MiB, less when many threads would pin more than 512 MiB in total
  * (pinning costs 0.16 ms/MiB and competes with the table upload for the runtime's lock) */
 static uint64_t lane_bytes(unsigned threads)
@@ -121,9 +140,7 @@ void Feeder::feedFile(const std::string &fn, uint64_t offset)
 {
 	SeqReader rd;
 	if (!rd.open(fn, offset)) {
-		std::lock_guard<std::mutex> lk(g_stderr);
-		std::cerr << "file " << fn << " cannot be opened" << std::endl;
-		exit(1);
+		fatal("file " + fn + " cannot be opened");
 	} else if (m_opt.verbose && offset == 0) {
 		std::lock_guard<std::mutex> lk(g_stderr);
 		std::cerr << "Opening " << fn << std::endl;
@@ -573,8 +590,7 @@ void FingerPrint::drainEarly()
 	}
 	for (auto &th : pool) th.join();
 	if (m_early->failed()) {                                    /* reads were lost (no memory for a chunk, the file's rest unreadable): never print counts */
-		std::cerr << "ntsmCount: " << m_early->error() << ": " << ntsm_strerror(NTSM_ERR_NOMEM) << std::endl;
-		exit(1);
+		fatal("ntsmCount: " + m_early->error() + ": " + ntsm_strerror(NTSM_ERR_NOMEM));
 	}
 	if (m_opt.phase_times)
 		std::cerr << "[phase] " << m_opt.inputs[0] << ": early ingest (" << m_early->how() << ") parsed " << m_early->records() << " records ("
@@ -619,8 +635,7 @@ void FingerPrint::fetchResults()
 	if (rc == 0) rc = ntsm_sync(m_ctx[0], &m_totals);
 	if (rc == 0) rc = ntsm_counts(m_ctx[0], m_counts.data());
 	if (rc) {
-		std::cerr << "ntsmCount: cannot fetch counts: " << ntsm_strerror(rc) << std::endl;
-		exit(1);
+		fatal(std::string("ntsmCount: cannot fetch counts: ") + ntsm_strerror(rc));
 	}
 	m_fetched = true;
 }

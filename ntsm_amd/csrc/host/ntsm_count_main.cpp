@@ -128,6 +128,7 @@ int main(int argc, char *argv[])
 		{ "snp", required_argument, NULL, 's' },     { "kmer", required_argument, NULL, 'k' },
 		{ "gpu", required_argument, NULL, 'g' },     { "help", no_argument, NULL, 'h' },
 		{ "version", no_argument, &OPT_VERSION, 1 }, { "verbose", no_argument, NULL, 'v' },
+		{ "debug-fault", required_argument, NULL, 1000 },      /* tests only, not in the help text: KIND:NTH -> ntsm_debug_fail_after */
 		{ NULL, 0, NULL, 0 } };
 	int c, option_index = 0;
 	while ((c = getopt_long(argc, argv, "s:t:vhk:m:do:g:", long_options, &option_index)) != -1) {
@@ -153,6 +154,16 @@ int main(int argc, char *argv[])
 			break;
 		}
 		case 'v': opt.verbose++; break;
+		case 1000: {                                   /* fault injection for tests/test_gpu_parity.py: the NTH device allocation (KIND 1),
+		                                                * host-to-device copy (2) or pinned allocation (3) of this process fails */
+			int kind = 0;
+			long long nth = 0;
+			if (sscanf(optarg, "%d:%lld", &kind, &nth) != 2 || ntsm_debug_fail_after(kind, nth) < 0) {
+				std::cerr << "Error - Invalid parameter debug-fault: " << optarg << std::endl;
+				return 0;
+			}
+			break;
+		}
 		case '?': die = true; break;
 		}
 	}

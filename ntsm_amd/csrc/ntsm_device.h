@@ -1,6 +1,6 @@
 /*
  * ntsm_device.h -- data layout and hash functions shared by the host table builder and the
- * gfx950 kernels (ntsm_hip.hip).
+ * gfx950 kernels (kernels_generic.hip, kernels_mz.hip).
  *
  * HBM layout of one context:
  *   filter      : 2^F bits (uint32 words); bit f(x) set for every site k-mer x.  Sized to stay in

@@ -1,0 +1,273 @@
+/*
+ * tables.cpp -- host-side construction of everything the count kernels look things up in: the 2-choice cuckoo key table
+ * (what tsl::robin_map<uint64_t, size_t> m_counts is in the reference: src/FingerPrint.hpp:466, filled by initCountsHash
+ * :490-564), the generic kernel's bit filter, the minimizer-blocked filter, the drain's second-level Bloom and the
+ * two-level path's minimizer Bloom.  Pure host code: no HIP call, no device code -- ntsm_create runs it
+ * while another thread may still be bringing the runtime up; runtime.cpp uploads the images.
+ *
+ * The hash functions are shared with the kernels (ntsm_device.h) so that both sides agree bit for bit.
+ */
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "ntsm_internal.h"
+
+namespace ntsm_rt {
+
+#ifndef NTSM_TABLE_LOAD
+#define NTSM_TABLE_LOAD 0.25                   /* cuckoo key table: slots >= keys / load, power of two.  A sparser table costs memory, not time
+                                                * (the Infinity Cache holds 128 MiB as well as 64): what a fuller one costs is the second-bucket probe of
+                                                * a key whose first bucket is full -- 903 / 889 / 856 / 833 Gbases/s at load <= 0.25 / 0.4 / 0.6 / 0.8 */
+#endif
+
+/* vendor/KseqHashIterator.hpp:114-127 restated as data for the kernel's LDS table */
+void build_lut(uint8_t *lut)
+{
+	for (int i = 0; i < 256; ++i) lut[i] = 4;
+	for (int i = 0; i < 4; ++i) lut[i] = (uint8_t) i;
+	lut['A'] = lut['a'] = 0;
+	lut['C'] = lut['c'] = 1;
+	lut['G'] = lut['g'] = 2;
+	lut['T'] = lut['t'] = lut['U'] = lut['u'] = 3;
+}
+
+bool wants_two_level(uint64_t n_keys) { return (12ull * n_keys + 127) / 128 > (9ull << 15); }   /* 12 bits per key > 4.5 MiB */
+
+uint64_t mask_for_k(int k) { return k >= 32 ? 0ull : ((1ull << (2 * k)) - 1); }   /* k = 32: see include/ntsm_hip.h */
+
+#ifdef NTSM_WITH_TAB
+#include "ntsm_tab_tables.inc"
+#else
+static inline void build_tab_filter(ntsm_ctx *, int) {}
+#endif
+
+/* The structures are independent functions of the key set: built on four host threads (the cuckoo table dominates). */
+int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
+{
+	const uint32_t n = c->n_kmers;
+	/* The four structures are independent functions of the key set: built on four host threads (the cuckoo table
+	 * dominates), uploaded afterwards. */
+	std::vector<uint64_t> keys;
+	std::vector<uint32_t> &filter = img.filter, &blocks = img.blocks /* 4 words per block */, &prefilter = img.prefilter, &bloom = img.bloom;
+	filter.clear(); blocks.clear(); prefilter.clear(); bloom.clear();
+	int cuckoo_rc = NTSM_OK;
+	auto build_cuckoo = [&]() {
+		/* slots: power of two with load <= NTSM_TABLE_LOAD; at least 32 */
+		uint64_t slots = 32;
+		while ((double) n > NTSM_TABLE_LOAD * (double) slots) slots <<= 1;
+		for (;; slots <<= 1) {
+			const uint32_t blog = (uint32_t) __builtin_ctzll(slots >> 1);
+			const uint32_t bshift = 32 - blog;
+			keys.assign(slots, NTSM_EMPTY_KEY);
+			c->slot_of.assign(n, 0);
+			std::vector<uint32_t> owner(slots, 0);            /* dense index stored in each slot */
+			bool ok = true;
+			uint64_t rng = 0x9E3779B97F4A7C15ull;
+			/* 1.5 M keys go into 64 MB of slots at random: every insertion is two cache misses unless its two buckets are asked
+			 * for a few dozen keys ahead (0.055 s -> 0.015 s for the human set) */
+			constexpr uint32_t kAhead = 24;
+			auto buckets_of = [&](uint64_t key, uint64_t b[2]) {
+				const uint32_t f = ntsm_fold(key);
+				b[0] = 2ull * (ntsm_h1(f) >> bshift);
+				b[1] = 2ull * (ntsm_h2(f) >> bshift);
+			};
+			for (uint32_t i = 0; i < n && i < kAhead; ++i) {
+				uint64_t b[2];
+				buckets_of(c->canon[i], b);
+				__builtin_prefetch(&keys[b[0]], 1);
+				__builtin_prefetch(&keys[b[1]], 1);
+			}
+			for (uint32_t i = 0; i < n && ok; ++i) {
+				if (i + kAhead < n) {
+					uint64_t b[2];
+					buckets_of(c->canon[i + kAhead], b);
+					__builtin_prefetch(&keys[b[0]], 1);
+					__builtin_prefetch(&keys[b[1]], 1);
+				}
+				uint64_t key = c->canon[i];
+				uint32_t idx = i;
+				uint64_t b[2];
+				buckets_of(key, b);
+				/* duplicate check against both candidate buckets */
+				for (int q = 0; q < 2; ++q)
+					for (int s = 0; s < 2; ++s)
+						if (keys[b[q] + s] == key) { cuckoo_rc = NTSM_ERR_DUP_KEY; return; }
+				bool placed = false;
+				for (int kick = 0; kick < 1000 && !placed; ++kick) {
+					if (kick) buckets_of(key, b);
+					for (int q = 0; q < 2 && !placed; ++q)
+						for (int s = 0; s < 2 && !placed; ++s)
+							if (keys[b[q] + s] == NTSM_EMPTY_KEY) {
+								keys[b[q] + s] = key;
+								owner[b[q] + s] = idx;
+								c->slot_of[idx] = (uint32_t) (b[q] + s);
+								placed = true;
+							}
+					if (placed) break;
+					rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+					const uint64_t victim = b[(rng >> 33) & 1] + ((rng >> 34) & 1);
+					std::swap(key, keys[victim]);
+					std::swap(idx, owner[victim]);
+					c->slot_of[owner[victim]] = (uint32_t) victim;   /* the key that moved in; the one that moved out is placed next */
+				}
+				if (!placed) ok = false;
+			}
+			if (!ok) continue;                                /* grow and retry */
+			c->n_slots = slots;
+			c->bucket_log2 = blog;
+			break;
+		}
+	};
+	auto build_filter = [&]() {
+		/* filter: >= 8 bits per key, 2^16 .. 2^28 bits; F = 24 (2 MiB) for the 1.5 M-key human set */
+		uint32_t flog = 16;
+		while (flog < 28 && (1ull << flog) < 8ull * n) ++flog;
+		if (filter_log2_req >= 10 && filter_log2_req <= 30) flog = (uint32_t) filter_log2_req;
+		c->filter_log2 = flog;
+		filter.assign((1ull << flog) / 32, 0);
+		const uint32_t fshift = 32 - flog;
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t bit = ntsm_h1(ntsm_fold(c->canon[i])) >> fshift;
+			filter[bit >> 5] |= 1u << (bit & 31);
+		}
+	};
+	/* Two-level path (15 <= k <= 31): chosen when the blocked filter at 12 bits per key is far enough out of the L2 (more than
+	 * 4.5 MiB: beyond ~3.1 M site k-mers.  Measured one level / two levels: 1.9 M keys 797 / 665, 2.6 M 715 / 650, 4.0 M
+	 * 457 / 623, 8.0 M 292 / 530, 16 M 219 / 404 Gbases/s), or forced either way with ntsm_set_kernel (4 / 2). */
+	c->two_level = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 1 &&
+		(c->kernel_variant == 4 || (c->kernel_variant == 0 && filter_log2_req == 0 && wants_two_level(n)));
+	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k, c->two_level);
+	auto build_blocks = [&]() {
+		/* minimizer-addressed blocked filter (k = 19 and the other k of ntsm_fast_plan).  Size = smallest of {2^e,
+		 * 3 * 2^(e-2)} blocks with at least 12 bits per key: 3 MiB for the 1.54 M-key human set -- it must leave room in the
+		 * 4 MiB per-XCD L2 for the read stream and the bucket lines, a full 4 MiB filter misses L2 on 18 % of its reads. */
+		if (plan.mode >= 0) {
+			uint32_t e = 6, mult = 1;
+			if (filter_log2_req >= 100 && filter_log2_req <= 130) {          /* 100 + v: 3 * 2^v bits */
+				mult = 3; e = (uint32_t) (filter_log2_req - 100) - 7;
+			} else if (filter_log2_req >= 10 && filter_log2_req <= 30) {
+				e = (uint32_t) filter_log2_req - 7;
+			} else {
+				/* blocks: 12 bits per key; 16 on the two-level path, where the filter lives in the Infinity Cache anyway and a
+				 * false positive costs a bucket read from HBM (16 M keys: 32 MiB measured 400 Gbases/s against 391 at 24 MiB) */
+				const uint64_t want = ((c->two_level ? 16ull : 12ull) * n + 127) / 128;
+				while ((1ull << e) < want && e < 23) ++e;
+				if (e > 8 && (3ull << (e - 2)) >= want) { mult = 3; e -= 2; }   /* 0.75 * 2^e is enough */
+			}
+			if (e > 22) e = 22;
+			if (e < 4) e = 4;
+			c->n_blocks = (uint64_t) mult << e;
+			if (filter_log2_req == 0 && !c->two_level) {
+				/* One level, automatic: the index is a multiply-high range reduction, so the size need not be 2^e or 3 * 2^e.
+				 * 13.5 bits per key in steps of 64 KiB, at most 3 MiB: the filter shares the 4 MiB L2 with the stream and the
+				 * look-ups' lines, and past ~2.75 MiB every further bit per key is paid for in L2 misses.  Measured on the bench
+				 * set (1.54 M keys, 3e8 reads; 2 / 2.25 / 2.375 / 2.5 / 2.625 / 2.75 / 3 MiB): 862 / 883 / 888 / 891 / 888 / 885 /
+				 * 863 Gbases/s; 2.08 M keys: 3 MiB 777, 3.25 770; 2.56 M keys: 3 / 3.25 / 3.5 / 3.75 / 4 MiB: 718 / 721 / 722 / 711 / 716.
+				 * The cap only makes sense where a bigger set has somewhere else to go: k = 13, 14 have no 14-mer minimizers and a
+				 * context forced to one level (ntsm_set_kernel 2) must not fall back on a saturated 3 MiB filter -- those keep the
+				 * 2^e / 3 * 2^(e-2) ladder at >= 12 bits per key computed above (up to 64 MiB). */
+				const bool has_two_level_form = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 2 && c->kernel_variant != 3;   /* 3 (tabulated, make tab) is forced to one level too */
+				const uint64_t kib_want = std::max<uint64_t>(1, (27ull * n / 16 + 1023) / 1024);   /* 13.5 bits = 27/16 bytes per key */
+				if (has_two_level_form || kib_want <= 3072) {
+					const uint64_t kib = std::min<uint64_t>(3072, kib_want);
+					c->n_blocks = std::max<uint64_t>(16, ((kib + 63) / 64 * 64) * 64);
+					if (kib < 64) c->n_blocks = std::max<uint64_t>(16, kib * 64);
+				}
+			}
+			if (c->blocks_kib_req) c->n_blocks = (uint64_t) c->blocks_kib_req * 64;   /* tuning: any size, the index is a multiply-high range reduction */
+			c->blk_map.n_blocks = (uint32_t) c->n_blocks;
+			blocks.assign(c->n_blocks * 4, 0u);
+			std::vector<uint32_t> site_mz;                            /* two-level path: every site k-mer's minimizer */
+			if (c->two_level) site_mz.resize(n);
+			/* the minimizer of a key is eight hashes and a reverse complement (40 ns): with the table build down to 15 ms this
+			 * loop is what the four structures wait for, so it is cut into ranges of keys; the bits are OR-ed atomically */
+			auto fill_blocks = [&](uint32_t lo, uint32_t hi) {
+			for (uint32_t i = lo; i < hi; ++i) {
+				const uint64_t x = c->canon[i];
+				/* reverse complement of the 2k-bit code: complement, then reverse the 2-bit groups of the 64-bit word */
+				uint64_t rc = ~x;
+				rc = ((rc >> 2) & 0x3333333333333333ull) | ((rc & 0x3333333333333333ull) << 2);
+				rc = ((rc >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((rc & 0x0F0F0F0F0F0F0F0Full) << 4);
+				rc = __builtin_bswap64(rc) >> (64 - 2 * plan.k);
+				const uint32_t mmask = (1u << (2 * plan.m)) - 1u;
+				uint32_t mz = 0xFFFFFFFFu;
+				for (uint32_t j = plan.a; j < plan.a + plan.w; ++j) {     /* the candidate m-mer at offset j from the end, and its reverse complement */
+					const uint32_t sub = (uint32_t) (x >> (2 * j)) & mmask;
+					const uint32_t rsub = (uint32_t) (rc >> (2 * (plan.k - plan.m - j))) & mmask;
+					mz = std::min(mz, ntsm_mmer_hash_m(std::min(sub, rsub), plan.m));
+				}
+				if (c->two_level) site_mz[i] = mz;
+				const uint32_t u = ntsm_kmer_sum(ntsm_code_top(x, plan.k), ntsm_code_top(rc, plan.k)), um = ntsm_kmer_mix(u);
+				uint32_t *blk = &blocks[(size_t) ntsm_block_idx(mz, c->blk_map) * 4];
+				__atomic_fetch_or(&blk[0], 1u << NTSM_KBIT0(u), __ATOMIC_RELAXED);
+				__atomic_fetch_or(&blk[1], 1u << NTSM_KBIT1(um), __ATOMIC_RELAXED);
+				__atomic_fetch_or(&blk[2], 1u << NTSM_KBIT2(um), __ATOMIC_RELAXED);
+				__atomic_fetch_or(&blk[3], 1u << NTSM_KBIT3(um), __ATOMIC_RELAXED);
+			}
+			};
+			{
+				const uint32_t parts = n >= (1u << 18) ? 4u : 1u;
+				std::vector<std::thread> pool;
+				for (uint32_t t = 1; t < parts; ++t) pool.emplace_back(fill_blocks, (uint32_t) ((uint64_t) n * t / parts), (uint32_t) ((uint64_t) n * (t + 1) / parts));
+				fill_blocks(0, (uint32_t) ((uint64_t) n / parts));
+				for (auto &th : pool) th.join();
+			}
+			if (c->two_level) {
+				/* Bloom over the DISTINCT site minimizers: one 32-bit word per minimizer, two bits; 12 bits per distinct
+				 * minimizer, at most 2.25 MiB: it has to stay in the 4 MiB L2 beside the lines the block and bucket reads
+				 * pull through it (16 M keys, 1.75 / 2 / 2.25 / 2.5 / 3 MiB: 376 / 391 / 394 / 393 / 379 Gbases/s); any
+				 * word count will do, the index is a multiply-high range reduction */
+				std::sort(site_mz.begin(), site_mz.end());
+				site_mz.erase(std::unique(site_mz.begin(), site_mz.end()), site_mz.end());
+				c->n_site_minimizers = (uint32_t) site_mz.size();
+				const uint64_t want_w = std::max<uint64_t>(1024, std::min<uint64_t>(2304ull * 256, (12ull * site_mz.size() + 31) / 32));
+				const uint32_t nw = c->bloom_words_req ? c->bloom_words_req : (uint32_t) ((want_w + 31) & ~31ull);
+				c->n_bloom_words = nw;
+				bloom.assign(nw, 0u);
+				for (uint32_t mz : site_mz) {
+					const uint32_t h = ntsm_block_hash(mz);
+					bloom[ntsm_range(h, nw)] |= (1u << NTSM_BLOOM_BIT0(h)) | (1u << NTSM_BLOOM_BIT1(h));
+				}
+			}
+			NTSM_ABL_BLOCKS_BUILT(blocks)
+		}
+	};
+	auto build_prefilter = [&]() {
+		/* second-level filter of the fast path: plain Bloom, 2 bits per key in one 32-bit word, >= 5 bits per key
+		 * (1 MiB for the human set: with the 3 MiB first level it still fits the 4 MiB per-XCD L2) */
+		if (plan.mode >= 0) {
+			uint32_t pl = 10;
+			/* The drain's Bloom pays while it sits in the L2 beside the first level (1 MiB for the human set).  A set that takes
+			 * the two-level path is too big for that: its Bloom (16 MiB at 16 M keys) would be one more Infinity-Cache
+			 * request per positive in front of the bucket read it is meant to save -- so it is left out (4 KiB, every bit
+			 * set: always an L2 hit, always passes). */
+			const bool pass_all = c->two_level && !c->prefilter_forced;
+			while (!pass_all && pl < 28 && (1ull << pl) < 5ull * n) ++pl;
+			if (c->prefilter_log2_req && !pass_all) pl = c->prefilter_log2_req;
+			NTSM_ABL_PREFILTER_LOG2(pl)
+			if (pl < 10) pl = 10;
+			if (pl > 30) pl = 30;
+			c->prefilter_log2 = pl;
+			prefilter.assign((1ull << pl) / 32, pass_all ? 0xFFFFFFFFu : 0u);
+			const uint32_t pshift = 32 - (pl - 5);
+			for (uint32_t i = 0; i < n && !pass_all; ++i) {
+				const uint32_t f = ntsm_fold(c->canon[i]), g1 = ntsm_h1(f), g2 = ntsm_h2(f);
+				prefilter[g1 >> pshift] |= (1u << (g2 & 31u)) | (1u << ((g2 >> 5) & 31u));
+			}
+			NTSM_ABL_PREFILTER_BUILT(prefilter)
+		}
+	};
+	auto build_tblocks = [&]() { build_tab_filter(c, filter_log2_req); };   /* no-op in the default build */
+	{
+		std::thread t1(build_filter), t2(build_blocks), t3(build_prefilter), t4(build_tblocks);
+		build_cuckoo();
+		t1.join(); t2.join(); t3.join(); t4.join();
+	}
+	return cuckoo_rc;
+}
+
+} // namespace ntsm_rt

@@ -1371,6 +1371,146 @@ def test_cli_hands_its_teardown_to_a_child(nt, tmp_path):
     assert not live_ntsm()
 
 
+def _free_hbm():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_fault_injection_create_fails_cleanly_at_every_allocation_and_upload(nt, tmp_path):
+    """VERDICT round 4, missing #5: the failure paths of ntsm_create, provoked.  ntsm_debug_fail_after (compiled in, armed only
+    through the C ABI) makes the nth device allocation / the nth host-to-device copy fail.  First the calls one creation makes
+    are counted, then each of them is failed in turn: ntsm_create must return an error, hand out no context, and leave device
+    memory as it found it (hipMemGetInfo before / after); and the creation right after that works and counts correctly.
+    Reference contract: a run that cannot set itself up exits with a message (src/FingerPrint.hpp:51-57, :493-499)."""
+    from ntsm_amd.capi import FAULT_DEVICE_ALLOC, FAULT_H2D, NtsmError, debug_fail_after
+    synth = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.5, sites_path=str(tmp_path / "s.fa"))
+    sites = nt.Sites(str(tmp_path / "s.fa"))
+    bases, ends = synth.host_bytes(0, 3000), synth.read_end(3000)
+    fp = OracleFP(str(tmp_path / "s.fa"))
+    fp.process_flat(bases, ends)
+    want = fp.kmers()[2]
+    nt.Context(sites.keys).close()                                  # runtime, stream pool and allocator warmed up
+    try:
+        for kind in (FAULT_DEVICE_ALLOC, FAULT_H2D):
+            debug_fail_after(kind, 1 << 40)                         # armed far away: only counts
+            nt.Context(sites.keys).close()
+            n_calls = debug_fail_after(kind, 0)
+            assert 5 <= n_calls <= 40, (kind, n_calls)
+            for nth in range(1, n_calls + 1):
+                before = _free_hbm()
+                debug_fail_after(kind, nth)
+                with pytest.raises(NtsmError, match="ntsm_create"):
+                    nt.Context(sites.keys)
+                debug_fail_after(kind, 0)
+                assert _free_hbm() == before, (kind, nth, before, _free_hbm())
+            ctx = nt.Context(sites.keys)
+            ctx.submit(bases, ends)
+            assert np.array_equal(ctx.counts(), want)
+            ctx.close()
+    finally:
+        debug_fail_after(FAULT_DEVICE_ALLOC, 0)
+        debug_fail_after(FAULT_H2D, 0)
+
+
+def test_fault_injection_failed_rebuild_leaves_err_state_everywhere(nt, tmp_path):
+    """include/ntsm_hip.h: a table rebuild (ntsm_set_kernel changing the level, ntsm_set_tuning with a filter size) that fails half
+    way leaves no consistent set of tables; the context is marked failed and EVERY later counting / merging / reporting call
+    answers NTSM_ERR_STATE ("invalid state"), until ntsm_destroy -- which still releases everything."""
+    import torch
+    from ntsm_amd.capi import FAULT_DEVICE_ALLOC, FAULT_H2D, NtsmError, debug_fail_after
+    synth = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.5, sites_path=str(tmp_path / "s.fa"))
+    sites = nt.Sites(str(tmp_path / "s.fa"))
+    bases, ends = synth.host_bytes(0, 2000), synth.read_end(2000)
+    d = torch.from_numpy(bases).cuda()
+    nt.Context(sites.keys).close()
+    try:
+        for how, kind, nth in (("kernel", FAULT_DEVICE_ALLOC, 2), ("kernel", FAULT_H2D, 3), ("tuning", FAULT_DEVICE_ALLOC, 4), ("tuning", FAULT_H2D, 1)):
+            before = _free_hbm()
+            ctx = nt.Context(sites.keys)
+            ctx.submit(bases, ends)
+            ctx.sync()
+            debug_fail_after(kind, nth)
+            with pytest.raises(NtsmError):
+                ctx.set_kernel(4) if how == "kernel" else ctx.set_tuning(22, 0)      # both rebuild the tables
+            debug_fail_after(kind, 0)
+            calls = (lambda: ctx.sync(), lambda: ctx.counts(), lambda: ctx.submit(bases, ends), lambda: ctx.count_resident(d.data_ptr(), d.numel(), 0, 2000),
+                     lambda: ctx.open_lane(1 << 20, 1 << 12), lambda: ctx.reset(), lambda: ctx.set_kernel(0), lambda: ctx.set_tuning(0, 0),
+                     lambda: ctx.set_max_hits(5), lambda: ctx.counts_device(), lambda: ctx.import_reduced(), lambda: ctx.debug_stats(),
+                     lambda: ctx.set_batch_capacity(1 << 20, 1 << 12), lambda: ctx.get_timing())
+            for i, call in enumerate(calls):
+                with pytest.raises(NtsmError, match="invalid state"):
+                    call()
+            ctx.close()
+            assert _free_hbm() == before, (how, kind, nth)
+    finally:
+        debug_fail_after(FAULT_DEVICE_ALLOC, 0)
+        debug_fail_after(FAULT_H2D, 0)
+
+
+def test_fault_injection_lost_lane_batch_surfaces_from_lane_close(nt, tmp_path):
+    """A producer lane whose copy to the device fails has LOST a batch: the submit reports it, every later submit of that lane
+    and ntsm_lane_close report it again, the context is marked failed (ntsm_sync / ntsm_counts: NTSM_ERR_STATE) so the incomplete
+    counts cannot be fetched; the other lanes of the context can still be closed.  Bytes lanes and packed lanes."""
+    from ntsm_amd.capi import FAULT_H2D, NtsmError, debug_fail_after
+    synth = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.5, sites_path=str(tmp_path / "s.fa"))
+    sites = nt.Sites(str(tmp_path / "s.fa"))
+    bases, ends = synth.host_bytes(0, 2000), synth.read_end(2000)
+    reads = [bytes(bases[i * 151:i * 151 + 150]) for i in range(2000)]
+    try:
+        for packed in (False, True):
+            ctx = nt.Context(sites.keys)
+            good, bad = ctx.open_lane(1 << 20, 1 << 12, packed_only=packed), ctx.open_lane(1 << 20, 1 << 12, packed_only=packed)
+            send = (lambda lane: lane.submit_packed(reads)) if packed else (lambda lane: lane.submit(bases, ends))
+            send(good)
+            send(bad)
+            debug_fail_after(FAULT_H2D, 1)
+            with pytest.raises(NtsmError, match="lane_submit"):
+                send(bad)
+            debug_fail_after(FAULT_H2D, 0)
+            with pytest.raises(NtsmError, match="lane_submit"):          # sticky: no further batch of this lane is accepted
+                send(bad)
+            good.close()
+            with pytest.raises(NtsmError, match="ntsm_lane_close"):
+                bad.close()
+            for call in (ctx.sync, ctx.counts):
+                with pytest.raises(NtsmError, match="invalid state"):
+                    call()
+            ctx.close()
+    finally:
+        debug_fail_after(FAULT_H2D, 0)
+
+
+def test_cli_turns_device_failures_into_exit_1_one_message_no_counts(nt, tmp_path):
+    """Through the CLI (hidden test flag --debug-fault KIND:NTH -> ntsm_debug_fail_after): a device allocation that fails while
+    the context is created or a lane is opened, a pinned allocation that fails (survivable when it is the pool's), a host-to-device copy that fails in the
+    tables' upload or in the middle of the run -- each ends with exit status 1, ONE `ntsmCount:` line on stderr and NOTHING on
+    stdout (counts are printed only when everything was counted: no partial counts.txt).  The reference's contract for a run
+    that cannot go on is exit(1) with a message (src/FingerPrint.hpp:51-57, :493-499).  And the same command without the flag
+    still gives the reference's bytes."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    inp = os.path.join(G, "inputs")
+    base = ["-s", "sites200.fa"]
+    ok = subprocess.run([exe] + base + ["-t", "4", "reads2k.fq", "reads600.fq.gz"], cwd=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert ok.returncode == 0 and len(ok.stdout) > 1000
+    seen = set()
+    for threads in ("1", "4"):
+        for kind, nths in ((1, (1, 3, 6, 9, 12, 15, 18)), (2, (1, 4, 8, 10, 11, 12, 14)), (3, (1, 2, 3))):
+            for nth in nths:
+                p = subprocess.run([exe] + base + ["-t", threads, "--debug-fault", "%d:%d" % (kind, nth), "reads2k.fq", "reads600.fq.gz"], cwd=inp,
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                if p.returncode == 0:                               # the run makes fewer calls of that kind than nth: then it is simply a good run
+                    assert p.stdout == ok.stdout, (threads, kind, nth)
+                    continue
+                msgs = [l for l in p.stderr.decode().split("\n") if l.startswith("ntsmCount:")]
+                assert p.returncode == 1 and p.stdout == b"" and len(msgs) == 1, (threads, kind, nth, p.returncode, p.stdout[:80], p.stderr[-400:])
+                seen.add((kind, msgs[0].split(":")[1].strip()))
+    # device allocations and copies were really made to fail; a pinned allocation that fails is survivable by design (the pool
+    # is an optimisation: its slots are then pinned one by one), so kind 3 may well produce good runs only
+    assert {1, 2} <= {k for k, _ in seen}, seen
+    assert any("context" in m for _, m in seen) and any(("submit" in m or "lane" in m or "staging" in m) for _, m in seen), seen
+
+
 def test_cli_reads_from_pipes(nt):
     """`ntsmCount -s sites.fa <(zcat a.fq.gz) <(cat b.fq)`: inputs that are pipes (process substitution) give the bytes
     of the same run on the files, with -t 1 and -t 2."""

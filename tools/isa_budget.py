@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/isa_budget.py [out_dir] -- instruction budget of ntsm_count_mz_kernel<0, false, 128, false>'s main loop from the compiler's ISA.
 
-Compiles ntsm_amd/csrc/ntsm_hip.hip to gfx950 assembly, takes the basic blocks of the 8-position loop body (the
+Compiles ntsm_amd/csrc/kernels_mz.hip to gfx950 assembly, takes the basic blocks of the 8-position loop body (the
 block with the eight filter-block loads and the blocks it falls through to up to the loop's back edge) and prints
 the instruction counts by unit and by mnemonic, per 8 positions and per position.  With out_dir: also writes
 main_loop.s (the loop body as compiled) and isa_budget.txt."""
@@ -15,8 +15,8 @@ def main():
     out_dir = sys.argv[1] if len(sys.argv) > 1 else None
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only",
-                               "-o", asm, os.path.join(ROOT, "ntsm_amd/csrc/ntsm_hip.hip")], stderr=subprocess.DEVNULL, cwd=td)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-S", "--cuda-device-only",
+                               "-o", asm, os.path.join(ROOT, "ntsm_amd/csrc/kernels_mz.hip")], stderr=subprocess.DEVNULL, cwd=td)
         text = open(asm).read()
     body = text[text.index(KERNEL + ":"):]
     body = body[:body.index(".Lfunc_end")]

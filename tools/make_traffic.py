@@ -10,19 +10,21 @@ so half of the stream bytes are added back; the random 4/8/16-byte filter and ta
 import collections, csv, glob, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["ntsm_amd/csrc/ntsm_hip.hip", "ntsm_amd/csrc/ntsm_device.h"]
+KERNEL_SOURCES = ["ntsm_amd/csrc/kernels_mz.hip", "ntsm_amd/csrc/kernels_generic.hip", "ntsm_amd/csrc/kernels_common.h", "ntsm_amd/csrc/ntsm_hooks.h",
+                  "ntsm_amd/csrc/ntsm_device.h", "ntsm_amd/csrc/runtime.cpp", "ntsm_amd/csrc/tables.cpp"]
 
 
 def kernel_source_sha16():
-    """SHA-256 over everything that decides what runs on the device and how it is launched: the whole of ntsm_hip.hip
-    (kernels AND the launch code: grid heuristic, tile sizes), ntsm_device.h and the build flags of the library
-    (Makefile's HIPFLAGS line and the libntsm_hip.so recipe, where -D overrides of the build parameters would sit)."""
+    """SHA-256 over everything that decides what runs on the device and how it is launched: the kernel translation units and
+    their shared headers, runtime.cpp (the launch code: grid heuristic, tile sizes), tables.cpp (filter and table geometry),
+    ntsm_device.h and the build flags of the library (Makefile's HIPFLAGS line, the hiplib recipe and the libntsm_hip.so rule,
+    where -D overrides of the build parameters would sit)."""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         h.update(open(os.path.join(ROOT, f), "rb").read())
     mk = open(os.path.join(ROOT, "Makefile")).read().split("\n")
     for i, line in enumerate(mk):
-        if line.startswith("HIPFLAGS") or line.startswith("ntsm_amd/libntsm_hip.so:"):
+        if line.startswith("HIPFLAGS") or line.startswith("ntsm_amd/libntsm_hip.so:") or line.startswith("\tfor f in $(HIPLIB_DEV)") or line.startswith("\t$(HIPCC) $(HIPFLAGS) -shared -o $(1)"):
             h.update(line.encode())
             if line.startswith("ntsm_amd/libntsm_hip.so:") and i + 1 < len(mk):
                 h.update(mk[i + 1].encode())
