@@ -50,6 +50,12 @@ tab: ntsm_amd/libntsm_hip_tab.so
 ntsm_amd/libntsm_hip_tab.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR) $(HIPLIB_TAB)
 	$(call hiplib,$@,-DNTSM_WITH_TAB,build/obj_tab)
 
+# design-study build: the two-level form with 12-mer minimizers instead of 14-mers, i.e. a
+# minimizer Bloom in front of the one-level kernel's own blocks -- tools/mid_study.sh measures it on the 2.5 M-key set
+m12: ntsm_amd/libntsm_hip_m12.so
+ntsm_amd/libntsm_hip_m12.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR)
+	$(call hiplib,$@,-DNTSM_TWO_M=12,build/obj_m12)
+
 # ntsmEval all-pairs scoring: own library, own CLI
 ntsm_amd/libntsm_eval_hip.so: $(CSRC)/ntsm_eval.hip include/ntsm_eval_hip.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -shared -o $@ $(CSRC)/ntsm_eval.hip
@@ -85,4 +91,4 @@ build/gather_bench: tools/gather_bench.hip
 clean:
 	rm -rf build ntsm_amd/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle_all clean ablation abl_tab tab
+.PHONY: all oracle_all clean ablation abl_tab tab m12

@@ -163,11 +163,11 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 		auto mmer_g = [&]() -> uint32_t {
 			if (!GEN) {
 				const uint32_t cm = min(F & ((1u << (2 * MM)) - 1u), R >> (32 - 2 * MM));
-				return TWO ? ntsm_mmer_hash_wide(cm) : ntsm_mmer_hash(cm);
+				return ntsm_mmer_hash_m(cm, (uint32_t) MM);            /* folded: 12-mers one 24-bit multiply, 14-mers a full one */
 			}
 			const uint32_t fm = __builtin_amdgcn_alignbit(Fh, F, g_a2) & g_mmask;
 			const uint32_t rm = (uint32_t) (((((unsigned long long) R) << 32) | Ro) >> g_rsh) & g_mmask;
-			return TWO ? ntsm_mmer_hash_wide(min(fm, rm)) : ntsm_mmer_hash(min(fm, rm));   /* 14-mers / 12-mers */
+			return ntsm_mmer_hash_m(min(fm, rm), (uint32_t) MM);       /* 14-mers / 12-mers */
 		};
 		/* forward word of the window's first 16 bases (k < 16: its code, left-aligned) */
 		auto f_top = [&]() -> uint32_t { return (uint32_t) ((((((unsigned long long) Fh) << 32) | F) << g_fsh) >> 32); };
