@@ -32,9 +32,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r04_traffic.json"          # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
-STRESS_TRAFFIC_FILE = "r04_stress_traffic.json"
-N10_FULL_TRAFFIC_FILE = "r04_n10_full_traffic.json"
+TRAFFIC_FILE = "r05_traffic.json"          # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
+STRESS_TRAFFIC_FILE = "r05_stress_traffic.json"
+N10_FULL_TRAFFIC_FILE = "r05_n10_full_traffic.json"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 SITES_SEED, N_SITES, READ_SEED, READ_LEN, K = 20241218, 96287, 7, 150, 19
 
@@ -311,7 +311,13 @@ def config_sites(nt, torch, dev, local, tmp, label, what, sites_seed, n_sites, m
            "hits_per_pass": t.total_hits // reps, "site_gen_and_load_s": t_sites, "create_s": t_create,
            "fabric_read_requests_per_base_from_pmc": tj.get("fabric_read_requests_per_base") if tj else None,
            "l2_requests_per_base_from_pmc": tj.get("l2_requests_per_base") if tj else None,
-           "l2_misses_per_base_from_pmc": tj.get("l2_misses_per_base") if tj else None, "pmc_source": note,
+           "l2_misses_per_base_from_pmc": tj.get("l2_misses_per_base") if tj else None,
+           # memory side of the L2 (round 5): every fabric read is a 128-byte line; how many of them reach HBM cannot be counted on
+           # this stack (no Infinity-Cache / HBM counter in rocprofv3 on gfx950: profiles/r05_counters/) -- see hbm_note
+           "fabric_read_bytes_per_base_from_pmc": tj.get("fabric_read_bytes_per_base") if tj else None,
+           "avg_fabric_read_latency_l2_clocks_from_pmc": tj.get("avg_fabric_read_latency_l2_clocks") if tj else None,
+           "hbm_read_bytes_per_base": tj.get("hbm_read_bytes_per_base") if tj else None, "hbm_note": tj.get("hbm_note") if tj else None,
+           "pmc_source": note,
            "check": check}
     del d_bases
     torch.cuda.empty_cache()

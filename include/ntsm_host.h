@@ -72,6 +72,11 @@ int ntsm_host_early_ingest(const char *path, unsigned n_parsers, unsigned n_deco
 int ntsm_host_early_ingest_hand_over(const char *path, unsigned n_parsers, unsigned n_decoders, uint64_t block_bytes, uint64_t chunk_positions,
 		uint64_t max_chunks, unsigned n_consumers, uint64_t hand_over_after, uint8_t **text, uint64_t *n_text, uint64_t *n_reads, uint64_t *n_bases,
 		uint64_t *n_parallel, uint64_t *n_rest);
+/* Thread counts of the ingest pipeline (ntsm_amd/csrc/host/host_shape.hpp): the CPUs this process is granted = min(affinity
+ * mask, cgroup CPU quota), and the plan `ntsmCount -t threads_asked` follows on such a host (cpus = 0: this host's grant):
+ * out = { cpus, feeders, decoders of one big .gz, decoders while the sites still load }.  feeders + decoders <= 2 x cpus. */
+unsigned ntsm_host_granted_cpus(void);
+void ntsm_host_ingest_plan(unsigned threads_asked, unsigned cpus, unsigned out[4]);
 /* Test hook: the n-th chunk allocation of an early ingest from now on fails (0 = off).  The hooks above then return -3:
  * an allocation failure must surface as a failed run, never as a shorter one (the CLI exits 1 with a message and prints no
  * counts, like the reference for a file it cannot read: src/FingerPrint.hpp:51-57). */

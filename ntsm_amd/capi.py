@@ -107,6 +107,8 @@ _sig(HO, "ntsm_host_early_ingest", C.c_int, [C.c_char_p, C.c_uint, C.c_uint, C.c
 _sig(HO, "ntsm_host_early_ingest_hand_over", C.c_int, [C.c_char_p, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, u64p, u64p, u64p, u64p])
 _sig(HO, "ntsm_host_gunzip_parallel_chunk", None, [C.c_uint64])
 _sig(HO, "ntsm_host_gunzip_parallel_stats", None, [u64p])
+_sig(HO, "ntsm_host_granted_cpus", C.c_uint, [])
+_sig(HO, "ntsm_host_ingest_plan", None, [C.c_uint, C.c_uint, C.POINTER(C.c_uint)])
 _sig(HO, "ntsm_host_debug_early_alloc_fail", None, [C.c_long])
 _sig(HO, "ntsm_host_debug_gz_max_tail", None, [C.c_uint64])
 _sig(HO, "ntsm_host_flatten_parallel", C.c_int, [C.c_char_p, C.c_uint, C.c_uint64, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p, u64p, u64p, u64p])
@@ -222,6 +224,19 @@ def gunzip(path, engine=0, chunk=1 << 16):
 def gunzip_parallel_chunk(n_bytes):
     """Compressed bytes per chunk of the parallel plain-gzip decoder (engine >= 2); 0 = default."""
     HO.ntsm_host_gunzip_parallel_chunk(C.c_uint64(n_bytes))
+
+
+def granted_cpus():
+    """CPUs this process is granted: min(affinity mask, cgroup CPU quota) -- host_shape.hpp"""
+    return int(HO.ntsm_host_granted_cpus())
+
+
+def ingest_plan(threads_asked, cpus=0):
+    """dict(cpus, feeders, decoders, early_decoders): the thread counts `ntsmCount -t threads_asked` uses on a host that grants `cpus`
+    CPUs (0: this one)."""
+    out = (C.c_uint * 4)()
+    HO.ntsm_host_ingest_plan(int(threads_asked), int(cpus), out)
+    return dict(cpus=out[0], feeders=out[1], decoders=out[2], early_decoders=out[3])
 
 
 def debug_early_alloc_fail(nth):

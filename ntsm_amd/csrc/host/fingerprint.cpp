@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include "early_ingest.hpp"
+#include "host_shape.hpp"
 #include "gz_stream.hpp"
 #include "pack2.hpp"
 #include "parallel_fastq.hpp"
@@ -282,6 +283,10 @@ size_t side_by_side_from(unsigned threads) { return std::max<size_t>(3, threads 
 
 FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 {
+	/* -t N is a ceiling: the threads that parse follow the CPUs this process is granted (affinity mask, cgroup quota), and the
+	 * decoder pools follow them (host_shape.hpp); counting into one table does not depend on the number */
+	m_plan = ingest_plan(std::max(1u, m_opt.threads), granted_cpus());
+	if (m_opt.threads > 1) m_opt.threads = std::max(2u, std::min(m_opt.threads, std::max(m_plan.feeders, 2u)));   /* 2 at least: keeps the lane path (and its tests) on a 1-CPU grant */
 	if (m_opt.devices.empty()) m_opt.devices.push_back(m_opt.device);
 	for (int d : m_opt.devices)
 		if (std::find(m_ctxDevice.begin(), m_ctxDevice.end(), d) == m_ctxDevice.end()) m_ctxDevice.push_back(d);
@@ -315,12 +320,11 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 		for (const std::string &fn : m_opt.inputs) n_big_gz += big_gzip_input(fn, m_opt.gz_parallel_min_bytes) ? 1 : 0;
 		const bool side_by_side = !getenv("NTSM_ZLIB_ONLY") && n_big_gz >= side_by_side_from(m_opt.threads);
 		if (m_opt.early && !side_by_side && m_opt.pack && m_opt.threads > 1 && !maybe_armed && m_opt.verbose <= 2 && !m_opt.inputs.empty()) {
-			const unsigned n_par = std::min(m_opt.threads, 16u);
-			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+			const unsigned n_par = std::min(m_opt.threads, std::max(1u, m_plan.feeders));
 			/* fewer than later, the start-up has threads of its own -- but the stream keeps these decoders to its end, also behind
 			 * the hand-over: 8 / 10 / 12 / 14 / 16 of them take the 12.6 GB file through in 1.29 / 1.14 / 1.00 / 0.91 / 0.94 s
 			 * (medians of five, one box, interleaved: profiles/r04_gz3/decoders_ab.txt) */
-			const unsigned n_dec = m_opt.gz_decoders ? m_opt.gz_decoders : std::min(std::min(14u, hw), 2 * m_opt.threads);
+			const unsigned n_dec = m_opt.gz_decoders ? m_opt.gz_decoders : m_plan.early_decoders;
 			const uint64_t chunk_pos = std::max<uint64_t>(4096, std::min<uint64_t>(std::max<uint64_t>(4096, m_opt.batch_bytes), lane_bytes(m_opt.threads))) & ~31ull;
 			/* 1.5 GiB of packed reads at most (4 Gbases): a gzip stream is handed over when the context is
 			 * there, so the chunks only ever hold what was parsed during the start-up -- 0.6 GB for the 12.6 GB file at 12 GB/s
@@ -446,12 +450,12 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 		 * fit one lane slot, so that no thread waits for its predecessor in the middle of a block */
 		if (!pf.open(fn, std::min<uint64_t>(m_opt.block_bytes, 2 * lane_bytes(m_opt.threads)))) { rest.push_back(fn); continue; }
 		const auto tp0 = std::chrono::steady_clock::now();
-		if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "block-parallel: " << pf.n_blocks() << " blocks, " << std::min<size_t>(want, 16) << " threads" << std::endl;
+		if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "block-parallel: " << pf.n_blocks() << " blocks, " << std::min<size_t>(want, m_plan.feeders) << " threads" << std::endl;
 		std::vector<Feeder *> sinks;
-		/* One plain FASTQ is parsed by at most 16 threads however many -t asks for: measured on a 256-thread host, 16
-		 * feeders parse + count at 50 Gbases/s, 32 at 40, 64 at 25 (they queue up on the runtime's submission path and on
-		 * the memory of the socket that holds the page cache); the result does not depend on the number. */
-		const size_t n_par = std::min<size_t>(want, 16);
+		/* One plain FASTQ is parsed by at most 16 threads however many -t asks for (host_shape.hpp's largest row): measured
+		 * on a 256-thread host, 16 feeders parse + count at 50 Gbases/s, 32 at 40, 64 at 25 (they queue up on the runtime's
+		 * submission path and on the memory of the socket that holds the page cache); the result does not depend on the number. */
+		const size_t n_par = std::min<size_t>(want, std::max(1u, m_plan.feeders));
 		{
 			std::vector<std::thread> mk;                         /* lanes (pinned staging) are allocated in parallel */
 			for (size_t t = 0; t < n_par; ++t) mk.emplace_back([this, t]() { (void) feederFor(t); });
@@ -484,16 +488,17 @@ void FingerPrint::computeCounts(const std::vector<std::string> &filenames)
 		const bool side_by_side = n_big >= side_by_side_from((unsigned) want);
 		for (const std::string &fn : rest) {
 			if (side_by_side || !is_big_gz(fn)) { small.push_back(fn); continue; }
-			const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-			/* decoder threads: twice the feeders, at most 16 -- measured on a 2 x 64-core host (6.3 GB of text, 1 MiB chunks, 16
-			 * feeders): 8 / 12 / 16 / 20 / 24 / 32 decoders inflate + parse + count in 0.74 / 0.51 / 0.42 / 0.48 / 0.47 / 0.52 s */
-			unsigned n_dec = (unsigned) std::min<size_t>(std::min<size_t>(16, hw), 2 * want);
+			/* decoder threads: as many as the grant has CPUs, at most twice the feeders (host_shape.hpp) -- measured under a 16-CPU
+			 * quota on a 2 x 64-core host (6.3 GB of text, 1 MiB chunks, 16 feeders): 8 / 12 / 16 / 20 / 24 / 32 decoders inflate +
+			 * parse + count in 0.74 / 0.51 / 0.42 / 0.48 / 0.47 / 0.52 s */
+			const size_t n_feed = std::min<size_t>(want, std::max(1u, m_plan.feeders));
+			unsigned n_dec = (unsigned) std::max<size_t>(1, std::min<size_t>(m_plan.decoders, 2 * n_feed));
 			if (m_opt.gz_decoders) n_dec = m_opt.gz_decoders;
 			GzStream::set_decoder_threads(n_dec);
 			std::unique_ptr<GzStream> gz(new GzStream());
 			if (!gz->open(fn)) { small.push_back(fn); continue; }
-			if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "parallel gzip: " << n_dec << " decoder threads, " << std::min<size_t>(want, 16) << " parsing threads" << std::endl;
-			countGzStream(std::move(gz), fn, 0, std::min<size_t>(want, 16));
+			if (m_opt.verbose) std::cerr << "Opening " << fn << "\n" << "parallel gzip: " << n_dec << " decoder threads, " << n_feed << " parsing threads" << std::endl;
+			countGzStream(std::move(gz), fn, 0, n_feed);
 		}
 		rest.swap(small);
 		GzStream::set_decoder_threads((unsigned) std::max<size_t>(1, m_opt.threads / std::max<size_t>(1, std::min(want, std::max<size_t>(1, rest.size())))));
@@ -550,7 +555,7 @@ void FingerPrint::countGzStream(std::unique_ptr<GzStream> gz, const std::string 
 void FingerPrint::drainEarly()
 {
 	const auto t0 = std::chrono::steady_clock::now();
-	const size_t n_par = std::min<size_t>(m_lanes.size(), 16);
+	const size_t n_par = std::min<size_t>(m_lanes.size(), std::max(1u, m_plan.feeders));
 	if (m_opt.verbose) std::cerr << "Opening " << m_opt.inputs[0] << "\n" << "early ingest (" << m_early->how() << "): parsed while the sites were loading" << std::endl;
 	{
 		std::vector<std::thread> mk;                         /* lanes (pinned staging) are allocated in parallel */

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../../include/ntsm_hip.h"
+#include "host_shape.hpp"
 #include "site_set.hpp"
 
 namespace ntsm {
@@ -121,6 +122,7 @@ private:
 	void fetchResults();
 
 	Options m_opt;
+	IngestPlan m_plan { 1, 1, 1, 1 };                       /* thread counts from the CPUs granted (host_shape.hpp) */
 	SiteSet m_sites;
 	uint64_t m_maxCounts = 0;
 	Feeder &feederFor(size_t t);                         /* thread t's lane on device devices[t % n] (created on first use) */

@@ -11,6 +11,7 @@
 #include "gz_stream.hpp"
 #include "pack2.hpp"
 #include "early_ingest.hpp"
+#include "host_shape.hpp"
 #include "parallel_fastq.hpp"
 #include "parallel_gz_fastq.hpp"
 #include "report.hpp"
@@ -323,6 +324,14 @@ int ntsm_host_early_ingest_hand_over(const char *path, unsigned n_parsers, unsig
 	if (n_parallel) *n_parallel = ei.parallel_records();
 	if (n_rest) *n_rest = rest_reads;
 	return through_chunks == ei.records() ? 0 : -2;
+}
+
+unsigned ntsm_host_granted_cpus(void) { return ntsm::granted_cpus(); }
+
+void ntsm_host_ingest_plan(unsigned threads_asked, unsigned cpus, unsigned out[4])
+{
+	const ntsm::IngestPlan p = ntsm::ingest_plan(threads_asked, cpus ? cpus : ntsm::granted_cpus());
+	out[0] = p.cpus; out[1] = p.feeders; out[2] = p.decoders; out[3] = p.early_decoders;
 }
 
 void ntsm_host_debug_gz_max_tail(uint64_t bytes) { ntsm::ParallelGzFastq::set_max_tail((size_t) bytes); }

@@ -755,6 +755,69 @@ def test_early_ingest_allocation_failure_is_an_error_not_a_shorter_run(nt, tmp_p
         debug_early_alloc_fail(0)
 
 
+_AFFINITY_PROBE = r"""
+import json, os, sys, threading, time
+sys.path.insert(0, %r)
+n, path = int(sys.argv[1]), sys.argv[2]
+os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:n]))
+from ntsm_amd.capi import granted_cpus, ingest_plan, early_ingest, flatten_file_parallel_gz, gunzip_parallel_chunk
+plan = ingest_plan(16)                                   # what `ntsmCount -t 16` does on a host that grants n CPUs
+base = len(os.listdir('/proc/self/task'))
+peak, stop = [0], [False]
+def watch():
+    while not stop[0]:
+        peak[0] = max(peak[0], len(os.listdir('/proc/self/task'))); time.sleep(0.0003)
+w = threading.Thread(target=watch); w.start()
+gunzip_parallel_chunk(20000)
+b, e, info = flatten_file_parallel_gz(path, plan['decoders'], plan['feeders'], 1 << 20)
+p_gz, peak[0] = peak[0] - base - 1, 0
+text, n_reads, n_bases, n_par = early_ingest(path, plan['feeders'], plan['early_decoders'], 1 << 20, 60000, 64, 1)
+p_early = peak[0] - base - 1 - 1                         # minus the watcher and the harness's one consumer thread
+stop[0] = True; w.join()
+import hashlib
+runs = sorted(r for r in text.split(b'N') if r)
+flat = sorted(r for r in bytes(b).split(b'N') if r)      # inside a piece the order of the records may differ: compare as multisets
+print(json.dumps(dict(granted=granted_cpus(), plan=plan, peak_gz=p_gz, peak_early=p_early, n_reads=len(e), early_reads=n_reads,
+                      flat_sha=hashlib.sha256(b'N'.join(flat)).hexdigest(), early_sha=hashlib.sha256(b'N'.join(runs)).hexdigest())))
+"""
+
+
+def test_ingest_thread_counts_follow_the_cpus_granted(nt, tmp_path):
+    """the feeder / decoder counts used to be constants fitted to the 16-CPU pod.  They now come from a
+    table keyed on the CPUs the process is GRANTED -- min(affinity mask, cgroup quota): host_shape.hpp -- and the host library's
+    ingest path is driven here (no GPU) under affinity masks of 2, 4 and 8 CPUs with the plan `-t 16` gets there: the same
+    reads (identical packed bytes, as multisets of runs for the early ingest whose chunk order is free) as on the unrestricted
+    host, and never more ingest threads than 2 x CPUs (+ one coordinator thread that only waits)."""
+    from ntsm_amd.capi import granted_cpus, ingest_plan
+    have = len(os.sched_getaffinity(0))
+    assert granted_cpus() <= have
+    for cpus in (1, 2, 3, 4, 6, 8, 12, 16, 24, 64, 256):
+        for asked in (1, 2, 4, 16, 64):
+            p = ingest_plan(asked, cpus)
+            assert p["cpus"] == cpus and 1 <= p["feeders"] <= min(asked, cpus, 16) and p["feeders"] == min(asked, cpus, 16)
+            assert 1 <= p["decoders"] <= 2 * p["feeders"] and 1 <= p["early_decoders"] <= 2 * asked
+            assert p["feeders"] + p["decoders"] + 1 <= max(2 * cpus, 3) + (1 if cpus >= 16 else 0), (asked, cpus, p)
+    assert ingest_plan(16, 16) == dict(cpus=16, feeders=16, decoders=16, early_decoders=14)      # the measured row (rounds 3-4)
+    s = nt.SynthShort(sites_seed=11, n_sites=200, read_seed=5, p_embed=0.2)
+    fq = str(tmp_path / "t.fq")
+    s.write_fastq(fq, 0, 60000)
+    gz = str(tmp_path / "t.fq.gz")
+    open(gz, "wb").write(_gz_member(open(fq, "rb").read(), 6))
+    script = str(tmp_path / "probe.py")
+    open(script, "w").write(_AFFINITY_PROBE % ROOT)
+    seen = {}
+    for n in (2, 4, 8, have):
+        if n > have:
+            continue
+        p = subprocess.run([sys.executable, script, str(n), gz], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        d = json.loads(p.stdout.decode().strip().split("\n")[-1])
+        assert d["granted"] == n and d["plan"]["cpus"] == n and d["n_reads"] == d["early_reads"] == 60000
+        assert d["peak_gz"] <= 2 * n + 1 and d["peak_early"] <= 2 * n + 1, d
+        seen[n] = (d["flat_sha"], d["early_sha"])
+    assert len(set(seen.values())) == 1, seen                     # identical bytes whatever the grant
+
+
 def test_early_ingest_packs_the_same_reads(nt, tmp_path):
     """early_ingest.hpp: the first input file parsed into packed chunks in ordinary memory while the sites load.  The chunks
     of a plain FASTQ and of the same reads as .gz hold the same reads as the sequential reader delivers: same number of reads
