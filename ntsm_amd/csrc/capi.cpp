@@ -607,6 +607,11 @@ int ntsm_set_tuning(ntsm_ctx *c, int filter_log2_bits, int grid_blocks)
 	int rc = ntsm_sync(c, nullptr);
 	if (rc) return rc;
 	c->grid_blocks = grid_blocks;
+	if (filter_log2_bits >= 4000000 && filter_log2_bits < 4000016) {   /* 4000000 + v: memory kinds of block filter (v & 3) and key table (v >> 2) */
+		c->blocks_mem_kind = (unsigned) (filter_log2_bits - 4000000) & 3u;
+		c->keys_mem_kind = ((unsigned) (filter_log2_bits - 4000000) >> 2) & 3u;
+		filter_log2_bits = 1000000 + (int) (c->bloom_words_req / 256u);     /* falls into the rebuild below */
+	}
 	if (filter_log2_bits >= 3000000 && filter_log2_bits < 3000040) {   /* 3000000 + v: drain Bloom of 2^v bits (0: automatic again) */
 		c->prefilter_log2_req = (uint32_t) (filter_log2_bits - 3000000);
 		if (c->prefilter_log2_req && (c->prefilter_log2_req < 10 || c->prefilter_log2_req > 30)) { c->prefilter_log2_req = 0; return NTSM_ERR_ARG; }

@@ -41,8 +41,8 @@ constexpr int kMaxDevices = 64;
  * gates below.  Armed with (kind, n), the n-th call of that kind from then on does not reach the runtime and reports
  * hipErrorOutOfMemory (allocations) or hipErrorUnknown (copies) instead -- what the reference's `exit(1)` paths
  * (src/FingerPrint.hpp:51-57, :493-499) correspond to on a device. */
-hipError_t dev_malloc(void **p, size_t bytes);
-template <class T> inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc((void **) p, bytes); }
+hipError_t dev_malloc(void **p, size_t bytes, unsigned mem_kind = 0);   /* mem_kind: 0 ordinary, 1 fine-grained, 3 uncached (hipExtMallocWithFlags) */
+template <class T> inline hipError_t dev_malloc(T **p, size_t bytes, unsigned mem_kind = 0) { return dev_malloc((void **) p, bytes, mem_kind); }
 hipError_t pinned_malloc(void **p, size_t bytes);
 hipError_t h2d(void *dst, const void *src, size_t bytes);
 hipError_t h2d_async(void *dst, const void *src, size_t bytes, hipStream_t st);
@@ -126,6 +126,9 @@ struct ntsm_ctx {
 	uint32_t prefilter_log2_req = 0;           /* tuning: log2 of the drain Bloom's bits (0 = automatic) */
 	bool prefilter_forced = false;             /* tuning (code 2): keep the drain's Bloom on the two-level path as well */
 	int filter_log2_req = 0;                   /* tuning: what ntsm_set_tuning asked for (kept across rebuilds) */
+	/* tuning (ntsm_set_tuning 4000000 + v): memory kind of the block filter (v & 3) and of the key table ((v >> 2) & 3):
+	 * 0 ordinary device memory, 1 fine-grained, 3 uncached -- DESIGN.md section 4.2b "what a miss moves" */
+	unsigned blocks_mem_kind = 0, keys_mem_kind = 0;
 	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
 	uint32_t prefilter_log2 = 0;               /* log2(bits) */
 	NtsmBlockMap blk_map = { 1 };

@@ -42,9 +42,11 @@ static inline bool fault_fires(int kind)
 	return a > 0 && s == a;
 }
 
-hipError_t dev_malloc(void **p, size_t bytes)
+hipError_t dev_malloc(void **p, size_t bytes, unsigned mem_kind)
 {
 	if (fault_fires(1)) { *p = nullptr; return hipErrorOutOfMemory; }
+	if (mem_kind == 1) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+	if (mem_kind == 3) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
 	return hipMalloc(p, bytes);
 }
 
@@ -200,7 +202,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 		HIPCHK(h2d(c->d_prefilter, img.prefilter.data(), img.prefilter.size() * sizeof(uint32_t)));
 	}
 	if (!img.blocks.empty()) {
-		HIPCHK(dev_malloc(&c->d_blocks, img.blocks.size() * sizeof(uint32_t)));
+		HIPCHK(dev_malloc(&c->d_blocks, img.blocks.size() * sizeof(uint32_t), c->blocks_mem_kind));
 		HIPCHK(h2d(c->d_blocks, img.blocks.data(), img.blocks.size() * sizeof(uint32_t)));
 	}
 	{
@@ -212,7 +214,7 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 	if (c->d_slot_of) (void) hipFree(c->d_slot_of);
 	c->d_filter = nullptr; c->d_keys = nullptr; c->d_slot_of = nullptr;
 	HIPCHK(dev_malloc(&c->d_filter, img.filter.size() * sizeof(uint32_t)));
-	HIPCHK(dev_malloc(&c->d_keys, 2 * c->n_slots * sizeof(uint64_t)));   /* { key0, key1, count0, count1 } per bucket */
+	HIPCHK(dev_malloc(&c->d_keys, 2 * c->n_slots * sizeof(uint64_t), c->keys_mem_kind));   /* { key0, key1, count0, count1 } per bucket */
 	HIPCHK(dev_malloc(&c->d_slot_of, (n ? n : 1) * sizeof(uint32_t)));
 	HIPCHK(h2d(c->d_filter, img.filter.data(), img.filter.size() * sizeof(uint32_t)));
 	if (n) HIPCHK(h2d(c->d_slot_of, c->slot_of.data(), n * sizeof(uint32_t)));
