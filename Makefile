@@ -30,7 +30,7 @@ build/ntsmCount: $(HOSTSRC) $(HOST)/fingerprint.cpp $(HOST)/early_ingest.cpp $(H
 	    -Lntsm_amd -lntsm_hip -lz -pthread -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
 # libntsm_hip.so = two device translation units (the kernels + their launchers) and four host-only ones
-HIPLIB_DEV  := $(CSRC)/kernels_generic.hip $(CSRC)/kernels_mz.hip
+HIPLIB_DEV  := $(CSRC)/kernels_generic.hip $(CSRC)/kernels_mz.hip $(CSRC)/kernels_run.hip
 HIPLIB_HOST := $(CSRC)/tables.cpp $(CSRC)/runtime.cpp $(CSRC)/rccl_bind.cpp $(CSRC)/capi.cpp
 HIPLIB_HDR  := $(CSRC)/ntsm_internal.h $(CSRC)/kernels_common.h $(CSRC)/ntsm_hooks.h $(CSRC)/ntsm_device.h include/ntsm_hip.h
 HIPLIB_TAB  := $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_tab_launch.inc $(CSRC)/ntsm_tab_runtime.inc $(CSRC)/ntsm_tab_tables.inc

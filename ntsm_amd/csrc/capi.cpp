@@ -162,7 +162,7 @@ void ntsm_destroy(ntsm_ctx *c)
 	tab_release(c);                                        /* no-op in the default build */
 	for (auto &b : c->device_cache) (void) hipFree(b.first);
 	c->device_cache.clear();
-	void *ptrs[] = { c->d_bloom, c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
+	void *ptrs[] = { c->d_rblocks, c->d_bloom, c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
 	for (void *p : ptrs) if (p) (void) hipFree(p);
 	delete c;
 }
@@ -670,7 +670,8 @@ int ntsm_rccl_probe(void) { return rccl_available() ? NTSM_OK : NTSM_ERR_RCCL; }
 
 int ntsm_set_kernel(ntsm_ctx *c, int variant)
 {
-	if (!c || variant < 0 || variant > 4) return NTSM_ERR_ARG;
+	if (!c || variant < 0 || variant > 5) return NTSM_ERR_ARG;
+	if (variant == 5 && c->k != NTSM_FAST_K) return NTSM_ERR_ARG;   /* the run-anchored kernel exists for k = 19 */
 	if (variant == 3 && !kWithTab) return NTSM_ERR_ARG;    /* the tabulated kernel is not part of this build (make tab) */
 	if (variant == 4 && ntsm_fast_plan((uint32_t) c->k, true).m != NTSM_TWO_M) return NTSM_ERR_ARG;   /* 15 <= k <= 31 */
 	int rc = ntsm_sync(c, nullptr);
@@ -680,10 +681,10 @@ int ntsm_set_kernel(ntsm_ctx *c, int variant)
 	/* one-level and two-level filters are different tables (12-mer / 14-mer minimizers): a change of level rebuilds them */
 	/* (the tabulated kernel hands its exotic tiles to the ONE-level k = 19 kernel: variant 3 on a context that had chosen two
 	 * levels by itself rebuilds the one-level tables, otherwise those tiles would probe 14-mer-addressed blocks with 12-mers) */
-	const bool want_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && variant != 1 && variant != 3 &&
+	const bool want_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && variant != 1 && variant != 3 && variant != 5 &&
 		(variant == 4 || (variant == 0 && c->filter_log2_req == 0 && wants_two_level(c->n_kmers)));
 	(void) before;
-	if (variant != 1 && want_two != c->two_level) {
+	if ((variant != 1 && want_two != c->two_level) || (variant == 5) != (c->d_rblocks != nullptr)) {   /* variant 5 has a filter of its own */
 		HIPCHK(hipSetDevice(c->device));
 		rc = build_tables(c, c->filter_log2_req);
 		if (rc) { c->failed = true; return rc; }            /* old tables freed, new ones incomplete: the context is unusable */

@@ -145,6 +145,29 @@ NTSM_DHD uint32_t ntsm_kmer_mix(uint32_t u) { return u * 0x9E3779B1u; }
 #define NTSM_KBIT3(um) (31u - (((um) >> 8) & 31u))
 
 
+/* ---- k = 19 run-anchored path (kernels_run.hip) -------------------------------------------------
+ * Order key of a canonical 12-mer: (code * odd) mod 2^24 -- a BIJECTION of the 24-bit code, so two different 12-mers never
+ * tie -- in bits 8..31, the 12-mer's position mod 8 in the low bits (the kernel's sliding minimum thereby also says WHERE the
+ * minimizer sits; the low bits only decide between occurrences of the same 12-mer).  The device returns the whole 32-bit
+ * product (v_mul_u32_u24) and lets the shift by 8 drop the top byte; the host masks. */
+NTSM_DHD uint32_t ntsm_run_hash24(uint32_t canon)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (uint32_t) __umul24(canon, 0x9E3779u);
+#else
+	return (uint32_t) (((uint64_t) (canon & 0xFFFFFFu) * 0x9E3779u) & 0xFFFFFFu);
+#endif
+}
+/* reverse complement of a 16-base word (first base in the top bits) */
+NTSM_DHD uint32_t ntsm_rc16_word(uint32_t w)
+{
+	uint32_t y = ~w;
+	y = ((y >> 2) & 0x33333333u) | ((y & 0x33333333u) << 2);
+	y = ((y >> 4) & 0x0F0F0F0Fu) | ((y & 0x0F0F0F0Fu) << 4);
+	y = ((y >> 8) & 0x00FF00FFu) | ((y & 0x00FF00FFu) << 8);
+	return (y >> 16) | (y << 16);
+}
+
 /* ---- k = 19 tabulated path ("tab" kernel) ------------------------------------
  * Measured on gfx950 (profiles/r02_valu_rate.txt): every wave64 VALU instruction of a mixed stream occupies its
  * SIMD for ~4.2 cycles whatever the opcode and whatever the occupancy, so the count kernel's speed is its VALU

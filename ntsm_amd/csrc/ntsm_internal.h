@@ -5,6 +5,7 @@
  *
  *   kernels_generic.hip  generic-k count kernel + helper kernels, launch_generic / launch_gather / ...
  *   kernels_mz.hip       minimizer-blocked count kernels, launch_mz (+ the tabulated kernel in `make tab` builds)
+ *   kernels_run.hip      run-anchored count kernel (k = 19, one filter test per minimizer run), launch_run
  *   tables.cpp           host-side construction of the cuckoo key table and the filters (no HIP call, no device code)
  *   runtime.cpp          pools, staging slots, table upload, launch_count, the exact -m early stop (armed_batch)
  *   rccl_bind.cpp        RCCL bound with dlopen on first use; the group all-reduce of ntsm_allreduce
@@ -132,6 +133,8 @@ struct ntsm_ctx {
 	uint32_t *d_prefilter = nullptr;           /* second-level Bloom used by the drain */
 	uint32_t prefilter_log2 = 0;               /* log2(bits) */
 	NtsmBlockMap blk_map = { 1 };
+	uint4 *d_rblocks = nullptr;                /* run-anchored kernel (variant 5, k = 19): signatures of anchored 16-mers, 128-bit blocks by minimizer */
+	uint64_t n_rblocks = 0, n_rentries = 0;
 	ntsm_rt::TabState tab;                     /* empty unless built with NTSM_WITH_TAB */
 	int look_blocks = 0;
 	uint64_t n_launch[3] = { 0, 0, 0 };         /* count launches by kernel: tabulated, minimizer-blocked, generic */
@@ -190,6 +193,8 @@ namespace ntsm_rt {
 hipError_t launch_generic(const NtsmCountParams &p, unsigned grid, hipStream_t st, bool per_read);
 hipError_t launch_mz(const NtsmCountParams &p, unsigned grid, hipStream_t st, int mode, bool per_read, bool two_level);
 int mz_tile_bytes();                         /* stream bytes per tile of the minimizer-blocked kernels */
+hipError_t launch_run(const NtsmCountParams &p, unsigned grid, hipStream_t st);   /* kernels_run.hip: run-anchored kernel, k = 19 */
+int run_tile_bytes();
 hipError_t launch_gather(const uint64_t *table, const uint32_t *slot_of, uint32_t n, unsigned long long *dense, hipStream_t st);
 hipError_t launch_unpack(const uint32_t *codes, const uint16_t *valid, void *out, unsigned long long n16, hipStream_t st);
 hipError_t launch_table_init(uint64_t *table, unsigned long long n_buckets, hipStream_t st);
@@ -202,7 +207,7 @@ int launch_tab(ntsm_ctx *c, hipStream_t st, const NtsmCountParams &p, uint64_t h
 
 /* ---- tables.cpp: the four (five) structures as host images; no HIP call */
 struct TableImages {
-	std::vector<uint32_t> filter, blocks /* 4 words per block */, prefilter, bloom;
+	std::vector<uint32_t> filter, blocks /* 4 words per block */, prefilter, bloom, rblocks /* run-anchored kernel */;
 };
 bool wants_two_level(uint64_t n_keys);
 int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img);   /* NTSM_OK / NTSM_ERR_DUP_KEY; sets the geometry fields of *c */

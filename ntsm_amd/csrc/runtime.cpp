@@ -205,6 +205,12 @@ int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx
 		HIPCHK(dev_malloc(&c->d_blocks, img.blocks.size() * sizeof(uint32_t), c->blocks_mem_kind));
 		HIPCHK(h2d(c->d_blocks, img.blocks.data(), img.blocks.size() * sizeof(uint32_t)));
 	}
+	if (c->d_rblocks) (void) hipFree(c->d_rblocks);
+	c->d_rblocks = nullptr;
+	if (!img.rblocks.empty()) {
+		HIPCHK(dev_malloc(&c->d_rblocks, img.rblocks.size() * sizeof(uint32_t)));
+		HIPCHK(h2d(c->d_rblocks, img.rblocks.data(), img.rblocks.size() * sizeof(uint32_t)));
+	}
 	{
 		const int rct = tab_upload(c);                          /* no-op in the default build */
 		if (rct) return rct;
@@ -350,8 +356,14 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.bloom_words = c->n_bloom_words;
 	p.fk_k = plan.k; p.fk_m2 = 2 * plan.m; p.fk_a2 = 2 * plan.a;
 	const bool tab = fast && !per_read && tab_applies(c);       /* always false in the default build */
+	const bool runk = fast && !per_read && !tab && c->kernel_variant == 5 && c->d_rblocks && c->k == NTSM_FAST_K;   /* run-anchored kernel */
+	if (runk) {
+		p.blocks = c->d_rblocks;
+		p.blk_map.n_blocks = (uint32_t) c->n_rblocks;
+		p.blk_bytes = (uint32_t) (c->n_rblocks * 16);
+	}
 	if (fast && !tab) {                                     /* the minimizer-blocked kernels cut the stream into their own tiles */
-		const uint64_t ftile = (uint64_t) mz_tile_bytes();
+		const uint64_t ftile = (uint64_t) (runk ? run_tile_bytes() : mz_tile_bytes());
 		p.n_tiles = (hi - (uint64_t) p.t0 + ftile - 1) / ftile;
 	}
 	/* Grid: many more workgroups than fit on the chip at once (4 per CU), each walking ~8+ tiles.  A grid of
@@ -382,7 +394,10 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 		if (rct) return rct;
 		c->n_launch[0]++;
 	} else
-	if (fast) {
+	if (runk) {
+		HIPCHK(launch_run(p, (unsigned) grid, st));
+		c->n_launch[1]++;
+	} else if (fast) {
 		const hipError_t le = launch_mz(p, (unsigned) grid, st, plan.mode, per_read, c->two_level);
 		if (le == hipErrorInvalidValue) return NTSM_ERR_STATE;  /* no kernel for this plan */
 		HIPCHK(le);

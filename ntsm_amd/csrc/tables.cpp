@@ -262,10 +262,64 @@ int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 		}
 	};
 	auto build_tblocks = [&]() { build_tab_filter(c, filter_log2_req); };   /* no-op in the default build */
+	/* Run-anchored kernel (kernels_run.hip; ntsm_set_kernel 5, k = 19): per site k-mer the signature of its ANCHORED 16-mer in
+	 * the block of its minimizer.  With q bases to the left of the minimizer M (12-mer with the smallest order key, start offset
+	 * q = 0 .. 7) the k-mer holds M + 4 bases right (q <= 3: class R, bases q .. q+15) or 4 bases left + M (q >= 4: class L,
+	 * bases q-4 .. q+11).  The kernel's sliding minimum decides between equal 12-mers by their position in the lane's chunk, which
+	 * the host cannot know: the signature is set for EVERY offset at which the minimum key occurs (a 12-mer repeated inside 19
+	 * bases), so the filter has no false negatives.  Signature = the four block bits of the other kernels, taken from the
+	 * strand-symmetric sum u = E + rc(E) of the 16-mer's code and its reverse complement's. */
+	img.rblocks.clear();
+	c->n_rblocks = 0;
+	c->n_rentries = 0;
+	auto build_rblocks = [&]() {
+		if (c->kernel_variant != 5 || c->k != NTSM_FAST_K) return;
+		std::vector<uint32_t> hmin(n);
+		std::vector<uint8_t> where(n);                        /* bit q: the minimum key occurs at start offset q */
+		uint64_t entries = 0;
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint64_t x = c->canon[i];
+			uint64_t rc = ~x;
+			rc = ((rc >> 2) & 0x3333333333333333ull) | ((rc & 0x3333333333333333ull) << 2);
+			rc = ((rc >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((rc & 0x0F0F0F0F0F0F0F0Full) << 4);
+			rc = __builtin_bswap64(rc) >> (64 - 2 * NTSM_FAST_K);
+			uint32_t best = 0xFFFFFFFFu;
+			uint8_t at = 0;
+			for (uint32_t q = 0; q < 8; ++q) {
+				const uint32_t sub = (uint32_t) (x >> (2 * (7 - q))) & 0xFFFFFFu, rsub = (uint32_t) (rc >> (2 * q)) & 0xFFFFFFu;
+				const uint32_t h = ntsm_run_hash24(std::min(sub, rsub));
+				if (h < best) { best = h; at = (uint8_t) (1u << q); }
+				else if (h == best) at |= (uint8_t) (1u << q);
+			}
+			hmin[i] = best;
+			where[i] = at;
+			entries += (uint64_t) __builtin_popcount(at);
+		}
+		c->n_rentries = entries;
+		/* 16 bits per entry in steps of 64 KiB, at most 3 MiB (the filter lives in the 4 MiB L2 beside the stream); ntsm_set_tuning
+		 * (2000000 + KiB) overrides */
+		uint64_t kib = std::max<uint64_t>(64, std::min<uint64_t>(3072, (2 * entries / 1024 + 63) / 64 * 64));
+		if (c->blocks_kib_req) kib = c->blocks_kib_req;
+		c->n_rblocks = kib * 64;
+		img.rblocks.assign(c->n_rblocks * 4, 0u);
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint64_t x = c->canon[i];
+			uint32_t *blk = &img.rblocks[(size_t) ntsm_range(ntsm_block_hash(hmin[i]), (uint32_t) c->n_rblocks) * 4];
+			for (uint32_t q = 0; q < 8; ++q) {
+				if (!((where[i] >> q) & 1u)) continue;
+				const uint32_t E = q <= 3 ? (uint32_t) (x >> (2 * (3 - q))) : (uint32_t) (x >> (2 * (7 - q)));
+				const uint32_t u = E + ntsm_rc16_word(E), um = ntsm_kmer_mix(u);
+				blk[0] |= 1u << NTSM_KBIT0(u);
+				blk[1] |= 1u << NTSM_KBIT1(um);
+				blk[2] |= 1u << NTSM_KBIT2(um);
+				blk[3] |= 1u << NTSM_KBIT3(um);
+			}
+		}
+	};
 	{
-		std::thread t1(build_filter), t2(build_blocks), t3(build_prefilter), t4(build_tblocks);
+		std::thread t1(build_filter), t2(build_blocks), t3(build_prefilter), t4(build_tblocks), t5(build_rblocks);
 		build_cuckoo();
-		t1.join(); t2.join(); t3.join(); t4.join();
+		t1.join(); t2.join(); t3.join(); t4.join(); t5.join();
 	}
 	return cuckoo_rc;
 }
