@@ -56,6 +56,10 @@ m12: ntsm_amd/libntsm_hip_m12.so
 ntsm_amd/libntsm_hip_m12.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR)
 	$(call hiplib,$@,-DNTSM_TWO_M=12,build/obj_m12)
 
+# experiment builds of the same ABI: make xlib XNAME=run96 XFLAGS="-DNTSM_RUN_C=96 ..." -> ntsm_amd/libntsm_hip_run96.so (NTSM_HIP_LIB selects it)
+xlib:
+	$(call hiplib,ntsm_amd/libntsm_hip_$(XNAME).so,$(XFLAGS),build/obj_$(XNAME))
+
 # ntsmEval all-pairs scoring: own library, own CLI
 ntsm_amd/libntsm_eval_hip.so: $(CSRC)/ntsm_eval.hip include/ntsm_eval_hip.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -shared -o $@ $(CSRC)/ntsm_eval.hip
@@ -91,4 +95,4 @@ build/gather_bench: tools/gather_bench.hip
 clean:
 	rm -rf build ntsm_amd/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle_all clean ablation abl_tab tab m12
+.PHONY: all oracle_all clean ablation abl_tab tab m12 xlib

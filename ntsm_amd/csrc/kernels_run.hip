@@ -31,14 +31,23 @@
 namespace {
 
 #ifndef NTSM_RUN_C
-#define NTSM_RUN_C 128                                 /* stream bytes per thread and tile */
+#define NTSM_RUN_C 96                                  /* stream bytes per thread and tile: 96 leaves room for the queues at four workgroups per CU */
 #endif
 #ifndef NTSM_RUN_WAVES
-#define NTSM_RUN_WAVES 3                               /* waves per SIMD the register budget is held to (LDS: 51 KB per workgroup) */
+#define NTSM_RUN_WAVES 4                               /* waves per SIMD the register budget is held to (LDS: 39.6 KB per workgroup at C = 96) */
 #endif
 constexpr int kRunC = NTSM_RUN_C;
+#ifndef NTSM_RUN_CAND_AT
+#define NTSM_RUN_CAND_AT 32                            /* passing runs are expanded once this many are queued */
+#endif
+#ifndef NTSM_RUN_ABL
+#define NTSM_RUN_ABL 0                                 /* experiment builds only: 1 = records are dropped instead of processed, 2 = no expansion */
+#endif
 constexpr int kRunQueue = 128;                         /* run records per wave: < 64 left over + one position's burst of <= 64 */
-constexpr int kCandQueue = 128;                        /* passing runs per wave, same rule */
+constexpr int kCandAt = NTSM_RUN_CAND_AT;
+constexpr int kCandQueue = (kCandAt - 1 + 64 + 15) / 16 * 16;   /* passing runs per wave: < kCandAt left over + one batch's <= 64 */
+constexpr int kKmerAt = 32;                            /* queued k-mers are looked up (64 at a time) once this many wait */
+constexpr int kKmerQueue = 96;                         /* < kKmerAt left over + one expansion step's <= 64 */
 
 template <int C>
 __device__ __forceinline__ int ntsm_run_tile_addr(int row, int byte_in_row)
@@ -60,11 +69,19 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 	constexpr int VPT = C / 16, NB = C / 8;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * C];
 	__shared__ uint2 lut64[256];
-	__shared__ uint4 rq_all[kThreads / 64][kRunQueue];       /* run records: { F, Fh, key of M, first << 8 | last position } */
-	__shared__ uint4 cq_all[kThreads / 64][kCandQueue];      /* passing runs: the record, classes that passed in meta bits 24 / 25 */
+	/* A run record is 12 bytes: F (the last 16 bases as of the run's last position), W = { the 10 bases before them : 20 bits |
+	 * classes that passed : 2 (passing runs only) | spare : 2 | first position mod 16 : 4 | last position mod 16 : 4 }, K = order key
+	 * of the minimizer (hash << 8 | its position mod 16).  26 bases are all a run ever needs: its oldest window begins 18 + 7 bases
+	 * before its last position. */
+	__shared__ uint2 rq_all[kThreads / 64][kRunQueue];       /* run records: { F, W } */
+	__shared__ uint32_t rk_all[kThreads / 64][kRunQueue];    /*              K */
+	__shared__ uint2 cq_all[kThreads / 64][kCandQueue];      /* passing runs, same layout */
+	__shared__ uint32_t ck_all[kThreads / 64][kCandQueue];
+	__shared__ uint2 kq_all[kThreads / 64][kKmerQueue];      /* canonical codes of their k-mers, waiting for the look-up */
 	const int t = threadIdx.x;
 	const int lane = t & 63;
-	uint4 *rq = rq_all[t >> 6], *cq = cq_all[t >> 6];
+	uint2 *rq = rq_all[t >> 6], *cq = cq_all[t >> 6], *kq = kq_all[t >> 6];
+	uint32_t *rk = rk_all[t >> 6], *ck = ck_all[t >> 6];
 	lut64[t] = p.lut64[t];
 	const uint32_t bshift = p.bshift, n_blocks = p.blk_map.n_blocks;
 	const unsigned long long blk_base = (unsigned long long) p.blocks;
@@ -129,78 +146,116 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 		}
 		uint32_t mz_prev = 0, i0 = 0;
 		unsigned long long bad_prev = ~0ull;
-		uint32_t qn = 0, cn = 0;                             /* wave-uniform queue fills */
+		uint32_t qn = 0, cn = 0, kn = 0;                     /* wave-uniform queue fills */
 
-		/* ---- expansion of passing runs: every k-mer of the classes that passed is rebuilt and looked up ---- */
+		/* ---- look-up of the k-mers of passing runs, 64 at a time, two stages over consecutive calls so that no bucket load is
+		 * consumed by the call that issued it: (A) pop 64 canonical codes, issue the first bucket's load; (B, next call) compare
+		 * (bucket 2 only if bucket 1 is full -- the host inserts with that invariant), one counter update per hit ---- */
+		uint32_t l_klo = 0, l_khi = 0, l_g2 = 0;
+		unsigned long long l_b1 = 0;
+		uint4 l_ba = make_uint4(0, 0, 0, 0);
+		bool l_v = false;
+		auto lookup = [&](bool take) {
+			long long slot = -1;
+			if (l_v) {
+				if (l_ba.x == l_klo && l_ba.y == l_khi) slot = (long long) l_b1;
+				else if (l_ba.z == l_klo && l_ba.w == l_khi) slot = (long long) l_b1 + 1;
+				else if ((l_ba.x & l_ba.y) != 0xFFFFFFFFu && (l_ba.z & l_ba.w) != 0xFFFFFFFFu) {
+					const unsigned long long b2 = 2ull * (l_g2 >> bshift);
+					const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + 2ull * b2);
+					if (bb.x == l_klo && bb.y == l_khi) slot = (long long) b2;
+					else if (bb.z == l_klo && bb.w == l_khi) slot = (long long) b2 + 1;
+				}
+				if (slot >= 0) ++nh;
+			}
+			ntsm_add_hits(p, slot, lane);
+			l_v = false;
+			if (take) {
+				const uint32_t n = kn < 64 ? kn : 64;
+				kn -= n;
+				l_v = (uint32_t) lane < n;
+				if (l_v) {
+					const uint2 q = kq[kn + lane];
+					l_klo = q.x; l_khi = q.y;
+					const uint32_t fo = ntsm_fold(((unsigned long long) q.y << 32) | q.x), g1 = ntsm_h1(fo);
+					l_g2 = ntsm_h2(fo);
+					l_b1 = 2ull * (g1 >> bshift);
+					l_ba = *reinterpret_cast<const uint4 *>(p.keys + 2ull * l_b1);
+				}
+			}
+		};
+
+		/* ---- expansion of passing runs: every k-mer of the classes that passed is rebuilt (no memory access) and queued ---- */
 		auto expand = [&]() {
 			const uint32_t n = cn < 64 ? cn : 64;
 			cn -= n;
 			const bool have = (uint32_t) lane < n;
-			uint4 r = make_uint4(0, 0, 0, 0);
-			if (have) r = cq[cn + lane];
-			const uint32_t pc = r.z & 15u, i1 = r.w & 0xFFu, ib = (r.w >> 8) & 0xFFu, cls = (r.w >> 24) & 3u;
-			const uint32_t o1 = (i1 - pc) & 15u, o0 = o1 - (i1 - ib);
-			const unsigned long long ctx = ((unsigned long long) r.y << 32) | r.x;
+			uint2 r = make_uint2(0, 0);
+			uint32_t rkey = 0;
+			if (have) { r = cq[cn + lane]; rkey = ck[cn + lane]; }
+			const uint32_t i1 = r.y & 15u, len1 = (i1 - (r.y >> 4)) & 15u, cls = (r.y >> 10) & 3u, fh = r.y >> 12;
+			const uint32_t o1 = (i1 - rkey) & 15u, o0 = o1 - len1;
 #pragma unroll 1
 			for (uint32_t step = 0; step < 8; ++step) {
 				const uint32_t o = o0 + step;                    /* bases to the right of M in this window */
 				const bool act = have && o <= o1 && ((o >= 4u ? cls & 1u : cls & 2u) != 0u);
 				if (__builtin_amdgcn_ballot_w64(have && o <= o1) == 0ull) break;
-				long long slot = -1;
+				const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+				if (am == 0ull) continue;
 				if (act) {
-					const unsigned long long fw = (ctx >> (2u * (o1 - o))) & 0x3FFFFFFFFFull;
-					unsigned long long y = ~fw;                  /* reverse complement of the 38-bit code */
-					y = ((y >> 2) & 0x3333333333333333ull) | ((y & 0x3333333333333333ull) << 2);
-					y = ((y >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((y & 0x0F0F0F0F0F0F0F0Full) << 4);
-					y = ((y >> 8) & 0x00FF00FF00FF00FFull) | ((y & 0x00FF00FF00FF00FFull) << 8);
-					y = ((y >> 16) & 0x0000FFFF0000FFFFull) | ((y & 0x0000FFFF0000FFFFull) << 16);
-					y = (y >> 32) | (y << 32);
-					const unsigned long long rc = y >> (64 - 38);
-					const unsigned long long key = fw < rc ? fw : rc;
-					const uint32_t klo = (uint32_t) key, khi = (uint32_t) (key >> 32);
-					const uint32_t fo = ntsm_fold(key), g1 = ntsm_h1(fo), g2 = ntsm_h2(fo);
-					const unsigned long long b1 = 2ull * (g1 >> bshift);
-					const uint4 ba = *reinterpret_cast<const uint4 *>(p.keys + 2ull * b1);
-					if (ba.x == klo && ba.y == khi) slot = (long long) b1;
-					else if (ba.z == klo && ba.w == khi) slot = (long long) b1 + 1;
-					else if ((ba.x & ba.y) != 0xFFFFFFFFu && (ba.z & ba.w) != 0xFFFFFFFFu) {
-						const unsigned long long b2 = 2ull * (g2 >> bshift);
-						const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + 2ull * b2);
-						if (bb.x == klo && bb.y == khi) slot = (long long) b2;
-						else if (bb.z == klo && bb.w == khi) slot = (long long) b2 + 1;
-					}
-					if (slot >= 0) ++nh;
+					/* the window ends o1 - o bases before the record's newest base: its last 16 bases and the 3 before them; the reverse
+					 * complement strand is the reversed last 16 followed by the reversed first 3 */
+					const uint32_t sh = 2u * (o1 - o);
+					const uint32_t lo = __builtin_amdgcn_alignbit(fh, r.x, sh), t3 = (fh >> sh) & 63u;
+					const uint32_t rl = ntsm_rc16(lo), n3 = ~t3;
+					const uint32_t r3 = ((n3 & 3u) << 4) | (n3 & 0xCu) | ((n3 >> 4) & 3u);
+					const uint32_t a_hi = t3, a_lo = lo, b_hi = rl >> 26, b_lo = (rl << 6) | r3;
+					const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
+					const uint32_t at = kn + __builtin_amdgcn_mbcnt_hi((uint32_t) (am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) am, 0u));
+					kq[at] = make_uint2(lt ? a_lo : b_lo, lt ? a_hi : b_hi);
 				}
-				ntsm_add_hits(p, slot, lane);
+				kn += (uint32_t) __popcll(am);
+				if (kn >= (uint32_t) kKmerAt) lookup(true);
 			}
 		};
 
 		/* ---- run processing, two stages over consecutive calls: (1) pop 64 records, request their blocks; (2) test ---- */
-		uint4 s_rec = make_uint4(0, 0, 0, 0), s_blk = make_uint4(0, 0, 0, 0);
+		uint2 s_rec = make_uint2(0, 0);
+		uint32_t s_key = 0;
+		uint4 s_blk = make_uint4(0, 0, 0, 0);
 		bool s_v = false;
 		auto process = [&](bool take) {
 			/* stage 2 */
 			uint32_t cls = 0;
 			if (s_v) {
-				const uint32_t pc = s_rec.z & 15u, i1 = s_rec.w & 0xFFu, ib = (s_rec.w >> 8) & 0xFFu;
-				const uint32_t o1 = (i1 - pc) & 15u, o0 = o1 - (i1 - ib);
-				/* E_R = M + 4 bases right ends 4 - o1 ... i.e. (o1 - 4) bases before the newest; E_L = 4 left + M ends o1 bases before it */
-				const uint32_t wR = __builtin_amdgcn_alignbit(s_rec.y, s_rec.x, (2u * (o1 - 4u)) & 31u);
-				const uint32_t wL = __builtin_amdgcn_alignbit(s_rec.y, s_rec.x, 2u * o1);
+				const uint32_t i1 = s_rec.y & 15u, len1 = (i1 - (s_rec.y >> 4)) & 15u, fh = s_rec.y >> 12;
+				const uint32_t o1 = (i1 - s_key) & 15u, o0 = o1 - len1;
+				/* E_R = M + 4 bases right ends o1 - 4 bases before the newest one; E_L = 4 bases left + M ends o1 bases before it */
+				const uint32_t wR = __builtin_amdgcn_alignbit(fh, s_rec.x, (2u * o1 - 8u) & 31u);
+				const uint32_t wL = __builtin_amdgcn_alignbit(fh, s_rec.x, 2u * o1);
 				const uint32_t uR = wR + ntsm_rc16(wR), uL = wL + ntsm_rc16(wL);
 				const uint32_t mR = ntsm_kmer_mix(uR), mL = ntsm_kmer_mix(uL);
-				const uint32_t tR = (s_blk.x >> NTSM_KBIT0(uR)) & (s_blk.y >> NTSM_KBIT1(mR)) & (s_blk.z >> NTSM_KBIT2(mR)) & (s_blk.w >> NTSM_KBIT3(mR)) & 1u;
-				const uint32_t tL = (s_blk.x >> NTSM_KBIT0(uL)) & (s_blk.y >> NTSM_KBIT1(mL)) & (s_blk.z >> NTSM_KBIT2(mL)) & (s_blk.w >> NTSM_KBIT3(mL)) & 1u;
-				cls = (o1 >= 4u ? tR : 0u) | (o0 <= 3u ? tL << 1 : 0u);
+				/* word << field puts the tested bit (31 - field, NTSM_KBITn) into the sign position; the shifter takes the low five bits
+				 * of the selected byte, and the sign of the AND of the four is the verdict (as in kernels_mz.hip's phase C) */
+				auto passes = [&](uint32_t u, uint32_t um) -> bool {
+					uint32_t s0, s1, s2, s3;
+					asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s0) : "v"(u), "v"(s_blk.x));
+					asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s1) : "v"(um), "v"(s_blk.y));
+					asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(s2) : "v"(um), "v"(s_blk.z));
+					asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(s3) : "v"(um), "v"(s_blk.w));
+					return (int32_t) (__builtin_amdgcn_bitop3_b32(s0, s1, s2, 0x80) & s3) < 0;
+				};
+				cls = (o1 >= 4u && passes(uR, mR) ? 1u : 0u) | (o0 <= 3u && passes(uL, mL) ? 2u : 0u);
 			}
 			const unsigned long long pm = __builtin_amdgcn_ballot_w64(cls != 0u);
-			if (pm) {
+			if (pm && NTSM_RUN_ABL != 2) {
 				if (cls) {
 					const uint32_t at = cn + __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
-					cq[at] = make_uint4(s_rec.x, s_rec.y, s_rec.z, s_rec.w | (cls << 24));
+					cq[at] = make_uint2(s_rec.x, s_rec.y | (cls << 10));
+					ck[at] = s_key;
 				}
 				cn += (uint32_t) __popcll(pm);
-				if (cn >= 64) expand();
+				if (cn >= (uint32_t) kCandAt) expand();
 			}
 			/* stage 1 */
 			s_v = false;
@@ -211,7 +266,8 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 				s_v = (uint32_t) lane < n;
 				if (s_v) {
 					s_rec = rq[qn + lane];
-					idx = ntsm_range(ntsm_block_hash(s_rec.z >> 8), n_blocks);
+					s_key = rk[qn + lane];
+					idx = ntsm_range(ntsm_block_hash(s_key >> 8), n_blocks);
 				}
 			}
 			const ntsm_u32x4 bv = ntsm_struct_buffer_load_b128(blk_rsrc, (int) idx, 0, 0, 0);
@@ -239,16 +295,18 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 				const unsigned long long endm = ~bad_prev & (chg | bad);     /* the lane's run ended with the previous position */
 				const unsigned long long startm = ~bad & (chg | bad_prev);
 				nk_s += (uint32_t) __popcll(~bad);
-				const uint32_t pos = (uint32_t) (b * 8 + j);
+				const uint32_t pos16 = pcb | (uint32_t) j;       /* position mod 16 (wave-uniform) */
 				if (endm) {
 					if (__builtin_amdgcn_inverse_ballot_w64(endm)) {
 						const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, 0u));
-						rq[at] = make_uint4(Fp, Fhp, mz_prev, (i0 << 8) | ((pos - 1u) & 0xFFu));
+						rq[at] = make_uint2(Fp, (Fhp << 12) | (i0 << 4) | ((pos16 - 1u) & 15u));
+						rk[at] = mz_prev;
 					}
 					qn += (uint32_t) __popcll(endm);
+					if (NTSM_RUN_ABL == 1) qn = 0;
 					if (qn >= 64) process(true);
 				}
-				i0 = __builtin_amdgcn_inverse_ballot_w64(startm) ? pos : i0;
+				i0 = __builtin_amdgcn_inverse_ballot_w64(startm) ? pos16 : i0;
 				mz_prev = mz;
 				bad_prev = bad;
 			}
@@ -261,7 +319,8 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 			if (endm) {
 				if (__builtin_amdgcn_inverse_ballot_w64(endm)) {
 					const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, 0u));
-					rq[at] = make_uint4(F, Fh, mz_prev, (i0 << 8) | (uint32_t) (C - 1));
+					rq[at] = make_uint2(F, (Fh << 12) | (i0 << 4) | (uint32_t) ((C - 1) & 15));
+					rk[at] = mz_prev;
 				}
 				qn += (uint32_t) __popcll(endm);
 			}
@@ -269,6 +328,8 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 		while (qn > 0) process(true);
 		process(false);                                     /* stage 2 of the last batch */
 		while (cn > 0) expand();
+		while (kn > 0) lookup(true);
+		lookup(false);
 #undef NTSM_RSTEP
 #undef NTSM_RKEY
 	}
