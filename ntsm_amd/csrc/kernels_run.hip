@@ -134,8 +134,11 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 			const uint4 v1 = *reinterpret_cast<const uint4 *>(tile + ntsm_run_tile_addr<C>(t, C - 16));
 			const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
 			uint32_t gw[8];
+			/* Only the last 22 of the 32 bytes in front of the chunk matter: a run of this chunk begins at a position >= 0, its
+			 * minimizer ends at most 7 bases before that and its left-anchored 16-mer 15 before the minimizer's end (22 back);
+			 * window 0 itself reaches 18 back.  Bases further back never enter a record that is read. */
 #pragma unroll
-			for (int i = 0; i < 32; ++i) {
+			for (int i = 10; i < 32; ++i) {
 				const uint2 e = lut64[(w[i >> 2] >> ((i & 3) * 8)) & 0xFFu];
 				NTSM_RSTEP(e)
 				if (i >= 25) gw[i - 24] = NTSM_RKEY(i & 15);
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 #pragma unroll
 			for (int j = 0; j < 8; ++j) e[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
 			uint32_t gg[8], pmin = 0xFFFFFFFFu;
-			const uint32_t pcb = (uint32_t) (b & 1) << 3;        /* wave-uniform: position mod 16 = pcb | j */
+			const uint32_t pcb = (uint32_t) __builtin_amdgcn_readfirstlane((b & 1) << 3);   /* scalar: position mod 16 = pcb | j */
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
 				const uint32_t Fp = F, Fhp = Fh;                 /* the words as of the previous position: what a run that ends there is recorded with */
@@ -298,15 +301,15 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 				const uint32_t pos16 = pcb | (uint32_t) j;       /* position mod 16 (wave-uniform) */
 				if (endm) {
 					if (__builtin_amdgcn_inverse_ballot_w64(endm)) {
-						const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, 0u));
-						rq[at] = make_uint2(Fp, (Fhp << 12) | (i0 << 4) | ((pos16 - 1u) & 15u));
+						const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, qn));
+						rq[at] = make_uint2(Fp, (Fhp << 12) | (i0 | ((pos16 - 1u) & 15u)));   /* i0 is kept shifted: first position mod 16 << 4 */
 						rk[at] = mz_prev;
 					}
 					qn += (uint32_t) __popcll(endm);
 					if (NTSM_RUN_ABL == 1) qn = 0;
 					if (qn >= 64) process(true);
 				}
-				i0 = __builtin_amdgcn_inverse_ballot_w64(startm) ? pos16 : i0;
+				i0 = __builtin_amdgcn_inverse_ballot_w64(startm) ? pos16 << 4 : i0;
 				mz_prev = mz;
 				bad_prev = bad;
 			}
@@ -318,8 +321,8 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 			const unsigned long long endm = ~bad_prev;
 			if (endm) {
 				if (__builtin_amdgcn_inverse_ballot_w64(endm)) {
-					const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, 0u));
-					rq[at] = make_uint2(F, (Fh << 12) | (i0 << 4) | (uint32_t) ((C - 1) & 15));
+					const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, qn));
+					rq[at] = make_uint2(F, (Fh << 12) | (i0 | (uint32_t) ((C - 1) & 15)));
 					rk[at] = mz_prev;
 				}
 				qn += (uint32_t) __popcll(endm);
