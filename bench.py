@@ -280,7 +280,8 @@ def config_sites(nt, torch, dev, local, tmp, label, what, sites_seed, n_sites, m
     t0 = time.perf_counter()
     ctx = nt.Context(sites.keys, k=K, device=local)
     t_create = time.perf_counter() - t0
-    two_level = ctx.debug_stats()["two_level"]
+    st = ctx.debug_stats()
+    two_level, run_form = st["two_level"], st.get("run_form", False)
     d_win = torch.from_numpy(s.windows).to(dev)
     asked = n_reads
     while True:
@@ -307,7 +308,7 @@ def config_sites(nt, torch, dev, local, tmp, label, what, sites_seed, n_sites, m
     tj, note = pmc_constants(traffic_file)
     out = {"workload": "%s: %.6g sites (%d site 19-mers), %.3g synthetic 150 bp reads" % (what["name"], n_sites, len(sites.keys), n_reads),
            "reads": n_reads, "reads_asked": asked, "site_kmers": len(sites.keys), "kernel_ms": ms, "gbases_per_s": bases / ms / 1e6,
-           "roofline_frac": bases * (READ_LEN + 8) / READ_LEN / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel_form": "two-level" if two_level else "one-level",
+           "roofline_frac": bases * (READ_LEN + 8) / READ_LEN / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel_form": "run-anchored" if run_form else "two-level" if two_level else "one-level",
            "hits_per_pass": t.total_hits // reps, "site_gen_and_load_s": t_sites, "create_s": t_create,
            "fabric_read_requests_per_base_from_pmc": tj.get("fabric_read_requests_per_base") if tj else None,
            "l2_requests_per_base_from_pmc": tj.get("l2_requests_per_base") if tj else None,

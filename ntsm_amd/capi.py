@@ -399,7 +399,7 @@ class Context:
         out = np.zeros(8, dtype=np.uint64)
         _chk(H.ntsm_debug_stats(self._h, _p(out, u64p)), "ntsm_debug_stats")
         return dict(exotic_tiles=int(out[0]), launches_tab=int(out[1]), launches_k19=int(out[2]), launches_generic=int(out[3]),
-                    queued_windows=int(out[4]), two_level=bool(out[5]), bloom_words=int(out[6]), site_minimizers=int(out[7]))
+                    queued_windows=int(out[4]), two_level=int(out[5]) == 1, run_form=int(out[5]) == 2, bloom_words=int(out[6]), site_minimizers=int(out[7]))
 
     @property
     def stream(self):

@@ -681,10 +681,11 @@ int ntsm_set_kernel(ntsm_ctx *c, int variant)
 	/* one-level and two-level filters are different tables (12-mer / 14-mer minimizers): a change of level rebuilds them */
 	/* (the tabulated kernel hands its exotic tiles to the ONE-level k = 19 kernel: variant 3 on a context that had chosen two
 	 * levels by itself rebuilds the one-level tables, otherwise those tiles would probe 14-mer-addressed blocks with 12-mers) */
-	const bool want_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && variant != 1 && variant != 3 && variant != 5 &&
+	const bool want_run = c->k == NTSM_FAST_K && (variant == 5 || (variant == 0 && c->filter_log2_req == 0 && !c->blocks_kib_req && wants_run_form(c->k, c->n_kmers)));
+	const bool want_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && variant != 1 && variant != 3 && !want_run &&
 		(variant == 4 || (variant == 0 && c->filter_log2_req == 0 && wants_two_level(c->n_kmers)));
 	(void) before;
-	if ((variant != 1 && want_two != c->two_level) || (variant == 5) != (c->d_rblocks != nullptr)) {   /* variant 5 has a filter of its own */
+	if (variant != 1 && (want_two != c->two_level || want_run != c->run_form)) {   /* the run form has a filter of its own */
 		HIPCHK(hipSetDevice(c->device));
 		rc = build_tables(c, c->filter_log2_req);
 		if (rc) { c->failed = true; return rc; }            /* old tables freed, new ones incomplete: the context is unusable */
@@ -713,7 +714,7 @@ int ntsm_debug_stats(ntsm_ctx *c, uint64_t out[8])
 	uint64_t dv[4] = { 0, 0, 0, 0 };
 	HIPCHK(hipMemcpy(dv, c->d_totals, sizeof dv, hipMemcpyDeviceToHost));
 	out[4] = dv[2];
-	out[5] = c->two_level ? 1 : 0;
+	out[5] = c->run_form ? 2 : c->two_level ? 1 : 0;
 	out[6] = c->n_bloom_words;
 	out[7] = c->n_site_minimizers;
 	return NTSM_OK;

@@ -46,8 +46,11 @@ constexpr int kRunC = NTSM_RUN_C;
 constexpr int kRunQueue = 128;                         /* run records per wave: < 64 left over + one position's burst of <= 64 */
 constexpr int kCandAt = NTSM_RUN_CAND_AT;
 constexpr int kCandQueue = (kCandAt - 1 + 64 + 15) / 16 * 16;   /* passing runs per wave: < kCandAt left over + one batch's <= 64 */
-constexpr int kKmerAt = 32;                            /* queued k-mers are looked up (64 at a time) once this many wait */
-constexpr int kKmerQueue = 96;                         /* < kKmerAt left over + one expansion step's <= 64 */
+#ifndef NTSM_RUN_KMER_AT
+#define NTSM_RUN_KMER_AT 32                            /* queued k-mers are looked up (64 at a time) once this many wait */
+#endif
+constexpr int kKmerAt = NTSM_RUN_KMER_AT;
+constexpr int kKmerQueue = (kKmerAt - 1 + 64 + 15) / 16 * 16;   /* < kKmerAt left over + one expansion step's <= 64 */
 
 template <int C>
 __device__ __forceinline__ int ntsm_run_tile_addr(int row, int byte_in_row)

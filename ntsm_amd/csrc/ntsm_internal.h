@@ -135,6 +135,7 @@ struct ntsm_ctx {
 	NtsmBlockMap blk_map = { 1 };
 	uint4 *d_rblocks = nullptr;                /* run-anchored kernel (variant 5, k = 19): signatures of anchored 16-mers, 128-bit blocks by minimizer */
 	uint64_t n_rblocks = 0, n_rentries = 0;
+	bool run_form = false;                     /* the run-anchored kernel counts unarmed batches: forced (ntsm_set_kernel 5) or chosen by size (wants_run_form) */
 	ntsm_rt::TabState tab;                     /* empty unless built with NTSM_WITH_TAB */
 	int look_blocks = 0;
 	uint64_t n_launch[3] = { 0, 0, 0 };         /* count launches by kernel: tabulated, minimizer-blocked, generic */
@@ -210,6 +211,7 @@ struct TableImages {
 	std::vector<uint32_t> filter, blocks /* 4 words per block */, prefilter, bloom, rblocks /* run-anchored kernel */;
 };
 bool wants_two_level(uint64_t n_keys);
+bool wants_run_form(int k, uint64_t n_keys);  /* k = 19 and 1.8 M <= keys < 7 M: kernels_run.hip beats both forms of kernels_mz.hip there */
 int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img);   /* NTSM_OK / NTSM_ERR_DUP_KEY; sets the geometry fields of *c */
 uint64_t mask_for_k(int k);
 void build_lut(uint8_t *lut);                /* vendor/KseqHashIterator.hpp:114-127 as data */

@@ -356,7 +356,7 @@ int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t l
 	p.bloom_words = c->n_bloom_words;
 	p.fk_k = plan.k; p.fk_m2 = 2 * plan.m; p.fk_a2 = 2 * plan.a;
 	const bool tab = fast && !per_read && tab_applies(c);       /* always false in the default build */
-	const bool runk = fast && !per_read && !tab && c->kernel_variant == 5 && c->d_rblocks && c->k == NTSM_FAST_K;   /* run-anchored kernel */
+	const bool runk = fast && !per_read && !tab && c->run_form && c->d_rblocks;   /* run-anchored kernel (k = 19; armed batches keep the per-read kernels) */
 	if (runk) {
 		p.blocks = c->d_rblocks;
 		p.blk_map.n_blocks = (uint32_t) c->n_rblocks;

@@ -37,6 +37,13 @@ void build_lut(uint8_t *lut)
 
 bool wants_two_level(uint64_t n_keys) { return (12ull * n_keys + 127) / 128 > (9ull << 15); }   /* 12 bits per key > 4.5 MiB */
 
+/* Run-anchored kernel or minimizer-blocked kernel?  Measured on 150 bp reads, site windows with all 13 k-mers kept (the clusters
+ * the run form feeds on), automatic minimizer-blocked form / run form, Gbases/s: 1.56 M keys 798 / 783, 2.0 M 715 / 773, 2.5 M 672 /
+ * 775, 3.4 M 619 / 753, 4.2 M 607 / 727, 5.7 M 568 / 640 (4 MiB filter), 8.3 M 522 / 545 (4 MiB); the bench set (1.54 M keys, 3 .. 13
+ * k-mers kept per window) 864 / 785.  Below 1.8 M keys the one-level minimizer-blocked filter still fits the L2 with room to
+ * spare and its main loop is the shorter one; from 7 M keys on the two-level form's minimizer Bloom is the better L2 resident. */
+bool wants_run_form(int k, uint64_t n_keys) { return k == NTSM_FAST_K && n_keys >= 1800000ull && n_keys < 7000000ull; }
+
 uint64_t mask_for_k(int k) { return k >= 32 ? 0ull : ((1ull << (2 * k)) - 1); }   /* k = 32: see include/ntsm_hip.h */
 
 #ifdef NTSM_WITH_TAB
@@ -138,7 +145,8 @@ int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 	/* Two-level path (15 <= k <= 31): chosen when the blocked filter at 12 bits per key is far enough out of the L2 (more than
 	 * 4.5 MiB: beyond ~3.1 M site k-mers.  Measured one level / two levels: 1.9 M keys 797 / 665, 2.6 M 715 / 650, 4.0 M
 	 * 457 / 623, 8.0 M 292 / 530, 16 M 219 / 404 Gbases/s), or forced either way with ntsm_set_kernel (4 / 2). */
-	c->two_level = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 1 &&
+	c->run_form = c->k == NTSM_FAST_K && (c->kernel_variant == 5 || (c->kernel_variant == 0 && filter_log2_req == 0 && !c->blocks_kib_req && wants_run_form(c->k, n)));
+	c->two_level = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 1 && !c->run_form &&
 		(c->kernel_variant == 4 || (c->kernel_variant == 0 && filter_log2_req == 0 && wants_two_level(n)));
 	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k, c->two_level);
 	auto build_blocks = [&]() {
@@ -273,7 +281,7 @@ int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 	c->n_rblocks = 0;
 	c->n_rentries = 0;
 	auto build_rblocks = [&]() {
-		if (c->kernel_variant != 5 || c->k != NTSM_FAST_K) return;
+		if (!c->run_form) return;
 		std::vector<uint32_t> hmin(n);
 		std::vector<uint8_t> where(n);                        /* bit q: the minimum key occurs at start offset q */
 		uint64_t entries = 0;
@@ -296,10 +304,12 @@ int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 			entries += (uint64_t) __builtin_popcount(at);
 		}
 		c->n_rentries = entries;
-		/* 16 bits per entry in steps of 64 KiB, at most 3 MiB (the filter lives in the 4 MiB L2 beside the stream); ntsm_set_tuning
-		 * (2000000 + KiB) overrides */
-		uint64_t kib = std::max<uint64_t>(64, std::min<uint64_t>(3072, (2 * entries / 1024 + 63) / 64 * 64));
-		if (c->blocks_kib_req) kib = c->blocks_kib_req;
+		/* 16 bits per entry in steps of 64 KiB, at most 3 MiB -- the filter lives in the 4 MiB L2 beside the stream (2.5 M keys: 2 / auto
+		 * 2.7 / 4 MiB measure 759 / 775 / 750 Gbases/s) -- and 4 MiB beyond 2.75 M entries (5.7 M keys: 3 / 4 MiB 621 / 640; 8.3 M: 482 /
+		 * 545: by then every bit saved costs more false look-ups than the L2 misses it avoids); ntsm_set_tuning(2000000 + KiB) with
+		 * ntsm_set_kernel(5) overrides */
+		uint64_t kib = std::max<uint64_t>(64, std::min<uint64_t>(entries < 2750000ull ? 3072 : 4096, (2 * entries / 1024 + 63) / 64 * 64));
+		if (c->blocks_kib_req && c->kernel_variant == 5) kib = c->blocks_kib_req;
 		c->n_rblocks = kib * 64;
 		img.rblocks.assign(c->n_rblocks * 4, 0u);
 		for (uint32_t i = 0; i < n; ++i) {

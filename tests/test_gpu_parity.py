@@ -143,13 +143,15 @@ def test_random_reads_vs_oracle_n10(nt, n10):
     _, _, ocnt = fp.kmers()
     # kernel variants (0 = minimizer-blocked fast path, 1 = generic, 4 = its two-level form with 14-mer minimizers and a
     # minimizer Bloom, which a set of this size would not take by itself) and filter / Bloom sizes must all agree
-    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (0, 124), (4, 0), (4, 214), (4, 266), (4, 22)):
+    # 5 = the run-anchored kernel (kernels_run.hip: one filter test per minimizer run on anchored 16-mers), with its automatic
+    # filter size and with 1 MiB / 6 MiB ones
+    for variant, flog in ((0, 0), (1, 0), (0, 20), (0, 27), (1, 18), (0, 124), (4, 0), (4, 214), (4, 266), (4, 22), (5, 0), (5, 2001024), (5, 2006144)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         if flog:
             ctx.set_tuning(flog, 0)
         st = ctx.debug_stats()
-        assert st["two_level"] == (variant == 4) and (st["bloom_words"] > 0) == (variant == 4), st
+        assert st["two_level"] == (variant == 4) and (st["bloom_words"] > 0) == (variant == 4) and st["run_form"] == (variant == 5), st
         if (variant, flog) == (4, 214):
             assert st["bloom_words"] == (1 << 14) // 32 and 300_000 < st["site_minimizers"] < len(sites.keys)
         half = (n // 2) * s.stride
@@ -280,8 +282,11 @@ def test_minimizer_fast_path_every_k(nt, tmp_path):
         bases, ends = nt.capi.flatten_reads(reads)
         fp.process_flat(bases, ends)
         want = fp.kmers()[2]
-        for variant in (0, 1) + ((4,) if k >= 15 else ()):     # 4: the two-level form (14-mer minimizers + minimizer Bloom), 15 <= k <= 31
+        for variant in (0, 1) + ((4,) if k >= 15 else ()) + ((5,) if k == 19 else ()):     # 4: the two-level form (14-mer minimizers + minimizer Bloom), 15 <= k <= 31; 5: the run-anchored kernel (k = 19)
             ctx = nt.Context(sites.keys, k=k)
+            if k != 19:
+                with pytest.raises(nt.NtsmError):
+                    ctx.set_kernel(5)                        # the run-anchored kernel exists for k = 19
             if variant == 4 or k >= 15:
                 ctx.set_kernel(variant)
             else:
@@ -292,7 +297,7 @@ def test_minimizer_fast_path_every_k(nt, tmp_path):
             t = ctx.sync()
             st = ctx.debug_stats()
             assert (st["launches_k19"] > 0) == (variant != 1) and (st["launches_generic"] > 0) == (variant == 1), (k, st)
-            assert st["two_level"] == (variant == 4), (k, st)
+            assert st["two_level"] == (variant == 4) and st["run_form"] == (variant == 5), (k, st)
             assert np.array_equal(ctx.counts(), want), (k, variant)
             assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases), (k, variant)
             ctx.close()
@@ -474,12 +479,15 @@ def test_random_reads_vs_oracle_n10_full(nt, tmp_path):
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)
     want = fp.kmers()[2]
     assert fp.total_hits > 150_000
-    for variant, tun in ((0, 0), (1, 0), (4, 0), (2, 0), (0, 2002048), (0, 3000021)):
+    # a set of this size takes the run-anchored kernel by itself (1.8 M <= keys < 7 M: measured 775 against 672 Gbases/s); 2 forces
+    # the one-level minimizer-blocked form, an explicit filter size (2000000 + KiB without ntsm_set_kernel 5) keeps it as well
+    for variant, tun in ((0, 0), (1, 0), (4, 0), (2, 0), (0, 2002048), (2, 3000021), (5, 0), (5, 2001536)):
         ctx = nt.Context(sites.keys)
         ctx.set_kernel(variant)
         if tun:
             ctx.set_tuning(tun, 0)
-        assert ctx.debug_stats()["two_level"] == (variant == 4), (variant, tun)
+        st = ctx.debug_stats()
+        assert st["two_level"] == (variant == 4) and st["run_form"] == ((variant, tun) in ((0, 0), (1, 0), (5, 0), (5, 2001536))), (variant, tun, st)
         ctx.submit(bases, ends)
         t = ctx.sync()
         assert np.array_equal(ctx.counts(), want), (variant, tun)
@@ -806,7 +814,7 @@ full = OracleFP(path); full.process_flat(bases, ends)
 thr = int(full.total_hits * 0.3)
 fp = OracleFP(path, cov=2.0 * (thr + 0.5) / len(sites.keys)); assert fp.max_hits == thr
 fp.process_flat(bases, ends); assert fp.early_term and fp.reads_processed > n0 + 1000
-for variant in (0, 1):                                   # minimizer-blocked, generic
+for variant in (0, 1, 5):                                # minimizer-blocked, generic, run-anchored (its spans; the crossing chunk goes per read through the minimizer-blocked kernel)
     ctx = nt.Context(sites.keys, max_hits=thr)
     ctx.set_kernel(variant)
     ctx.set_armed_chunk(1 << 20)
@@ -1194,7 +1202,7 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
         fp.L.ntsm_oracle_fp_insert_count(fp.h, buf.tobytes(), n)
         ends = np.array([n], dtype=np.uint64)
         flat = np.concatenate([buf, np.frombuffer(b"N", dtype=np.uint8)])
-        for variant in (0, 1) + ((4,) if k == 19 else ()):     # 4: the two-level form of the k = 19 kernel
+        for variant in (0, 1) + ((4, 5) if k == 19 else ()):     # 4: the two-level form of the k = 19 kernel, 5: the run-anchored kernel
             ctx = nt.Context(sites.keys, k=k)
             ctx.set_kernel(variant)
             ctx.submit(flat, ends)
@@ -1206,6 +1214,80 @@ def test_fuzz_arbitrary_bytes(nt, tmp_path):
     ctx = nt.Context(sites.keys, k=32)
     with pytest.raises(nt.NtsmError):                        # the two-level form exists for 15 <= k <= 31
         ctx.set_kernel(4)
+    ctx.close()
+
+
+def test_run_anchored_kernel_palindromes_repeats_and_short_runs(nt, tmp_path):
+    """kernels_run.hip decides once per minimizer RUN which k-mers are looked up, from the position of the minimizer inside the
+    k-mer; the inputs that stress that bookkeeping: site windows that are reverse-complement palindromes (a 12-mer and its twin
+    8 positions on carry the same order hash: the first version of the kernel took the pair for one run and lost 1 hit in 10^6),
+    tandem repeats of period 1 .. 7 (the minimum order key occurs several times inside one k-mer: the host sets the signature for
+    every occurrence), homopolymers, reads that are exactly one k-mer long, reads of k - 1 bases, reads made of a site window
+    interrupted by N every few bases, both strands.  Every kernel form against the oracle, unarmed and with a -m threshold."""
+    rng = np.random.default_rng(2024)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda x: "".join(comp[c] for c in reversed(x))
+    wins = []
+    for _ in range(150):
+        h = "".join(rng.choice(list("ACGT"), size=16))
+        wins.append((h + rc(h))[:31] if rng.random() < 0.5 else (h[:15] + "A" + rc(h[:15])))          # even and odd palindromes
+    for period in range(1, 8):
+        for _ in range(12):
+            u = "".join(rng.choice(list("ACGT"), size=period))
+            wins.append((u * 31)[:31])
+    for _ in range(100):
+        a = "".join(rng.choice(list("ACGT"), size=31))
+        wins.append(a)
+        wins.append(a[:12] + a[:12] + a[24:])                                                           # a 12-mer repeated at distance 12
+    wins = list(dict.fromkeys(wins))
+    path = str(tmp_path / "odd.fa")
+    with open(path, "w") as f:
+        for i, w in enumerate(wins):
+            f.write(">s%d\n%s\n" % (i // 2, w))
+    sites = nt.Sites(path, allow_dupes=True)
+    reads = []
+    for w in wins:
+        for strand in (w, rc(w)):
+            reads.append(strand.encode())
+            reads.append(("".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 40)))) + strand + "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 40))))).encode())
+            for s0 in range(0, 13, 3):
+                reads.append(strand[s0:s0 + 19].encode())                                               # exactly one k-mer
+            reads.append(strand[:18].encode())                                                          # too short for any
+            b = list(strand * 3)
+            for q in range(int(rng.integers(5, 30)), len(b), int(rng.integers(20, 40))):
+                b[q] = "N"
+            reads.append("".join(b).encode())
+    bases, ends = nt.capi.flatten_reads(reads)
+    fp = OracleFP(path, dupes=True)
+    fp.process_flat(bases, ends)
+    want = fp.kmers()[2]
+    assert fp.total_hits > 20000
+    for variant, tun in ((5, 0), (5, 2000064), (0, 0), (1, 0)):
+        ctx = nt.Context(sites.keys)
+        ctx.set_kernel(variant)
+        if tun:
+            ctx.set_tuning(tun, 0)
+        for rep in range(3):                                    # different batch splits: different alignments of the same reads to the lanes' chunks
+            cut = (len(reads) * (rep + 1)) // 4
+            cb = int(ends[cut - 1]) + 1
+            ctx.submit(bases[:cb], ends[:cut])
+            ctx.submit(bases[cb:], ends[cut:] - np.uint64(cb))
+        t = ctx.sync()
+        assert np.array_equal(ctx.counts(), want * np.uint64(3)), (variant, tun)
+        assert (t.total_kmers, t.total_hits, t.total_bases) == (3 * fp.total_kmers, 3 * fp.total_hits, 3 * fp.total_bases), (variant, tun)
+        ctx.close()
+    thr = fp.total_hits // 3
+    fm = OracleFP(path, dupes=True, cov=2.0 * (thr + 0.5) / len(sites.keys))
+    assert fm.max_hits == thr
+    fm.process_flat(bases, ends)
+    assert fm.early_term
+    ctx = nt.Context(sites.keys, max_hits=thr)
+    ctx.set_kernel(5)
+    ctx.set_armed_chunk(1 << 12)
+    ctx.submit(bases, ends)
+    t = ctx.sync()
+    assert t.early_stop == 1 and t.reads_consumed == fm.reads_processed and np.array_equal(ctx.counts(), fm.kmers()[2])
+    assert (t.total_kmers, t.total_hits, t.total_bases) == (fm.total_kmers, fm.total_hits, fm.total_bases)
     ctx.close()
 
 
