@@ -177,7 +177,7 @@ int ntsm_reset(ntsm_ctx *ctx);
 int ntsm_set_timing(ntsm_ctx *ctx, int on);
 int ntsm_get_timing(ntsm_ctx *ctx, uint64_t *n_launches, double *total_ms);
 /* Tuning knobs (0 = automatic): log2 of filter bits (rebuilds the tables: counts and totals restart from zero; 100 + v =
- * 3 * 2^v bits; 2000000 + w = w KiB; 200 + v / 250 + v / 1000000 + w = size of the two-level path's minimizer Bloom, 2^v /
+ * 3 * 2^v bits; 2000000 + w = w KiB (with ntsm_set_kernel 5: the run form's filter; 4000000 + v: memory kind of filter / key table, an experiment that measured no effect); 200 + v / 250 + v / 1000000 + w = size of the two-level path's minimizer Bloom, 2^v /
  * 3 * 2^v bits / w KiB), grid blocks.
  * For profiling experiments. */
 int ntsm_set_tuning(ntsm_ctx *ctx, int filter_log2_bits, int grid_blocks);
@@ -187,13 +187,18 @@ int ntsm_set_armed_chunk(ntsm_ctx *ctx, uint64_t chunk_bytes);
 /* Kernel choice.  All choices give identical results.
  *   0  automatic: 13 <= k <= 31 the minimizer-blocked kernel, other k the generic kernel; 15 <= k <= 31 with a site set
  *      whose blocked filter is well out of the L2 (more than ~3.1 M k-mers) takes the two-level form of the kernel: 14-mer
- *      minimizers and a Bloom word over the distinct site minimizers in front of the block
+ *      minimizers and a Bloom word over the distinct site minimizers in front of the block;
+ *      k = 19 with 1.8 M <= site k-mers < 7 M takes the run-anchored kernel (5) for unarmed batches
  *   1  always the generic kernel
  *   2  the minimizer-blocked kernel, one level, whatever the size of the set
  *   4  15 <= k <= 31 only: the two-level form, whatever the size of the set
+ *   5  k = 19 only: the run-anchored kernel (ntsm_amd/csrc/kernels_run.hip) -- one filter test per
+ *      minimizer run on the run's anchored 16-mers instead of one per k-mer -- whatever the size of the set; armed (-m)
+ *      batches of such a context still attribute hits per read with the minimizer-blocked kernel, whose one-level tables
+ *      are kept beside the run form's filter
  *   3  the tabulated k = 19 kernel, a measured negative result (7 % slower) that only exists in
  *      -DNTSM_WITH_TAB builds (`make tab`: ntsm_amd/libntsm_hip_tab.so); the default library answers NTSM_ERR_ARG.
- * One-level and two-level filters are different tables: a call that changes the level rebuilds them, and counts and
+ * One-level, two-level and run-form filters are different tables: a call that changes the form rebuilds them, and counts and
  * totals restart from zero (like ntsm_set_tuning with a filter size); variant 3 always counts with the one-level tables (its
  * exotic tiles go to the one-level k = 19 kernel), so it rebuilds them on a context that had chosen two levels.
  * A rebuild (here or in ntsm_set_tuning) that fails half way -- out of device memory -- leaves no consistent set of tables:
@@ -203,7 +208,7 @@ int ntsm_set_kernel(ntsm_ctx *ctx, int variant);
  * exact kernel because they hold bytes outside ACGTUNacgtun, out[1..3] = count launches by kernel
  * (tabulated, minimizer-blocked, generic), out[4] = windows that passed the tabulated kernel's first-level filter and
  * were queued for the look-up kernel (since creation or the last ntsm_reset), out[5] = 1 when the tables are the
- * two-level ones, out[6] = words of the minimizer Bloom, out[7] = distinct site minimizers (two-level tables). */
+ * two-level ones, 2 when the run-anchored kernel counts the unarmed batches, out[6] = words of the minimizer Bloom, out[7] = distinct site minimizers (two-level tables). */
 int ntsm_debug_stats(ntsm_ctx *ctx, uint64_t out[8]);
 /* Fault injection for tests of the failure paths (compiled into every build, armed ONLY through this call -- the library
  * reads no environment variable).  kind 1: device allocations, 2: host-to-device copies, 3: pinned host allocations.

@@ -31,14 +31,16 @@
 namespace {
 
 #ifndef NTSM_RUN_C
-#define NTSM_RUN_C 96                                  /* stream bytes per thread and tile: 96 leaves room for the queues at four workgroups per CU */
+#define NTSM_RUN_C 80                                  /* stream bytes per thread and tile: 80 leaves room for full-size queues at four workgroups per CU.  Measured
+                                                        * at 2.5 M keys (same box): C 128 / 3 workgroups 722 Gbases/s; C 96 with queues cut to fit four workgroups 777; C 80 with
+                                                        * full queues 789; C 64 / five workgroups 724 (the 22-base warm-up per chunk weighs more) */
 #endif
 #ifndef NTSM_RUN_WAVES
-#define NTSM_RUN_WAVES 4                               /* waves per SIMD the register budget is held to (LDS: 39.6 KB per workgroup at C = 96) */
+#define NTSM_RUN_WAVES 4                               /* waves per SIMD the register budget is held to (LDS: 38.1 KB per workgroup at C = 80); three instead of four costs 15 % */
 #endif
 constexpr int kRunC = NTSM_RUN_C;
 #ifndef NTSM_RUN_CAND_AT
-#define NTSM_RUN_CAND_AT 32                            /* passing runs are expanded once this many are queued */
+#define NTSM_RUN_CAND_AT 64                            /* passing runs are expanded once this many are queued */
 #endif
 #ifndef NTSM_RUN_ABL
 #define NTSM_RUN_ABL 0                                 /* experiment builds only: 1 = records are dropped instead of processed, 2 = no expansion */
@@ -47,7 +49,7 @@ constexpr int kRunQueue = 128;                         /* run records per wave: 
 constexpr int kCandAt = NTSM_RUN_CAND_AT;
 constexpr int kCandQueue = (kCandAt - 1 + 64 + 15) / 16 * 16;   /* passing runs per wave: < kCandAt left over + one batch's <= 64 */
 #ifndef NTSM_RUN_KMER_AT
-#define NTSM_RUN_KMER_AT 32                            /* queued k-mers are looked up (64 at a time) once this many wait */
+#define NTSM_RUN_KMER_AT 64                            /* queued k-mers are looked up (64 at a time) once this many wait */
 #endif
 constexpr int kKmerAt = NTSM_RUN_KMER_AT;
 constexpr int kKmerQueue = (kKmerAt - 1 + 64 + 15) / 16 * 16;   /* < kKmerAt left over + one expansion step's <= 64 */

@@ -12,7 +12,7 @@ Extra -D flags go to the compiler (e.g. -DNTSM_WITH_TAB)."""
 import hashlib, json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = ["ntsm_amd/csrc/kernels_generic.hip", "ntsm_amd/csrc/kernels_mz.hip"]
+SOURCES = ["ntsm_amd/csrc/kernels_generic.hip", "ntsm_amd/csrc/kernels_mz.hip", "ntsm_amd/csrc/kernels_run.hip"]
 
 
 def kernel_hashes(defs=(), sources=SOURCES):

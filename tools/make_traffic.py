@@ -10,7 +10,7 @@ so half of the stream bytes are added back; the random 4/8/16-byte filter and ta
 import collections, csv, glob, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["ntsm_amd/csrc/kernels_mz.hip", "ntsm_amd/csrc/kernels_generic.hip", "ntsm_amd/csrc/kernels_common.h", "ntsm_amd/csrc/ntsm_hooks.h",
+KERNEL_SOURCES = ["ntsm_amd/csrc/kernels_mz.hip", "ntsm_amd/csrc/kernels_run.hip", "ntsm_amd/csrc/kernels_generic.hip", "ntsm_amd/csrc/kernels_common.h", "ntsm_amd/csrc/ntsm_hooks.h",
                   "ntsm_amd/csrc/ntsm_device.h", "ntsm_amd/csrc/runtime.cpp", "ntsm_amd/csrc/tables.cpp"]
 
 
