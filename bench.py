@@ -552,7 +552,8 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp, singl
     sample, sample_gz, n_single, writer, job, t0s = single["sample"], single["sample_gz"], single["n"], single["writer"], single["job"], single["t0"]
     try:
         t0 = time.perf_counter()
-        gz_size = pigz_like(fq, gz, threads=max(1, min(48, int(host["cgroup_cpus"] or 0) or (os.cpu_count() or 2) - 1)))
+        # two CPUs of the grant are left to the single-threaded gzip that is still running beside this writer
+        gz_size = pigz_like(fq, gz, threads=max(1, min(48, (int(host["cgroup_cpus"] or 0) or (os.cpu_count() or 2)) - 2)))
         t_gz = time.perf_counter() - t0
         os.unlink(fq)
         job.wait()                                             # (started before the GPU legs; neither writer is timed)
