@@ -681,7 +681,7 @@ int ntsm_set_kernel(ntsm_ctx *c, int variant)
 	/* one-level and two-level filters are different tables (12-mer / 14-mer minimizers): a change of level rebuilds them */
 	/* (the tabulated kernel hands its exotic tiles to the ONE-level k = 19 kernel: variant 3 on a context that had chosen two
 	 * levels by itself rebuilds the one-level tables, otherwise those tiles would probe 14-mer-addressed blocks with 12-mers) */
-	const bool want_run = c->k == NTSM_FAST_K && (variant == 5 || (variant == 0 && c->filter_log2_req == 0 && !c->blocks_kib_req && wants_run_form(c->k, c->n_kmers)));
+	const bool want_run = choose_run_form(c, variant, c->filter_log2_req);
 	const bool want_two = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && variant != 1 && variant != 3 && !want_run &&
 		(variant == 4 || (variant == 0 && c->filter_log2_req == 0 && wants_two_level(c->n_kmers)));
 	(void) before;

@@ -212,6 +212,7 @@ struct TableImages {
 };
 bool wants_two_level(uint64_t n_keys);
 bool wants_run_form(int k, uint64_t n_keys);  /* k = 19 and 1.8 M <= keys < 7 M: kernels_run.hip beats both forms of kernels_mz.hip there */
+bool choose_run_form(const ntsm_ctx *c, int variant, int filter_log2_req);   /* forced (5), or automatic: size window + cluster structure */
 int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img);   /* NTSM_OK / NTSM_ERR_DUP_KEY; sets the geometry fields of *c */
 uint64_t mask_for_k(int k);
 void build_lut(uint8_t *lut);                /* vendor/KseqHashIterator.hpp:114-127 as data */

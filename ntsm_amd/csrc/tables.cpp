@@ -52,6 +52,66 @@ uint64_t mask_for_k(int k) { return k >= 32 ? 0ull : ((1ull << (2 * k)) - 1); } 
 static inline void build_tab_filter(ntsm_ctx *, int) {}
 #endif
 
+/* ---- run-anchored kernel (kernels_run.hip): what the host derives from one site k-mer --------------------------------------
+ * hmin = smallest order key among its eight canonical 12-mers, where = the start offsets q at which it occurs (bit q). */
+static inline void run_minimizer(uint64_t x, uint32_t *hmin, uint8_t *where)
+{
+	uint64_t rc = ~x;
+	rc = ((rc >> 2) & 0x3333333333333333ull) | ((rc & 0x3333333333333333ull) << 2);
+	rc = ((rc >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((rc & 0x0F0F0F0F0F0F0F0Full) << 4);
+	rc = __builtin_bswap64(rc) >> (64 - 2 * NTSM_FAST_K);
+	uint32_t best = 0xFFFFFFFFu;
+	uint8_t at = 0;
+	for (uint32_t q = 0; q < 8; ++q) {
+		const uint32_t sub = (uint32_t) (x >> (2 * (7 - q))) & 0xFFFFFFu, rsub = (uint32_t) (rc >> (2 * q)) & 0xFFFFFFu;
+		const uint32_t h = ntsm_run_hash24(std::min(sub, rsub));
+		if (h < best) { best = h; at = (uint8_t) (1u << q); }
+		else if (h == best) at |= (uint8_t) (1u << q);
+	}
+	*hmin = best;
+	*where = at;
+}
+/* strand-symmetric signature word of the anchored 16-mer of a k-mer whose minimizer starts at offset q: q <= 3: M + 4 bases
+ * right = bases q .. q+15 (class R); q >= 4: 4 bases left + M = bases q-4 .. q+11 (class L) */
+static inline uint32_t run_signature(uint64_t x, uint32_t q)
+{
+	const uint32_t E = q <= 3 ? (uint32_t) (x >> (2 * (3 - q))) : (uint32_t) (x >> (2 * (7 - q)));
+	return E + ntsm_rc16_word(E);
+}
+
+/* Does the site set have the cluster structure the run form feeds on?  ntsm's site files list the k-mers of one 31-base window
+ * one after the other, and the k-mers of a window that share a minimizer share their anchored 16-mer: on such a set far fewer
+ * distinct (minimizer, signature) pairs than k-mers exist (2.5 M keys of 13 per window: 0.55 per key).  A set of unrelated k-mers
+ * has one pair per key: the filter then holds no fewer entries than the minimizer-blocked one while every run still pays two
+ * tests -- the automatic choice leaves such a set to the other kernels.  Estimated on four stretches of 8,192 consecutive keys. */
+static bool run_form_pays(const ntsm_ctx *c)
+{
+	const uint32_t n = c->n_kmers;
+	if (n < 64) return false;
+	uint64_t keys = 0, distinct = 0;
+	const uint32_t stretch = std::min<uint32_t>(8192, n / 4);
+	for (uint32_t part = 0; part < 4; ++part) {
+		const uint32_t lo = (uint32_t) ((uint64_t) n * part / 4);
+		uint32_t ph = 0xFFFFFFFFu, pu = 0;
+		for (uint32_t i = lo; i < lo + stretch; ++i) {
+			uint32_t h; uint8_t at;
+			run_minimizer(c->canon[i], &h, &at);
+			const uint32_t u = run_signature(c->canon[i], (uint32_t) __builtin_ctz(at));
+			++keys;
+			if (h != ph || u != pu) ++distinct;
+			ph = h; pu = u;
+		}
+	}
+	return 10 * distinct <= 8 * keys;
+}
+
+bool choose_run_form(const ntsm_ctx *c, int variant, int filter_log2_req)
+{
+	if (c->k != NTSM_FAST_K) return false;
+	if (variant == 5) return true;
+	return variant == 0 && filter_log2_req == 0 && !c->blocks_kib_req && wants_run_form(c->k, c->n_kmers) && run_form_pays(c);
+}
+
 /* The structures are independent functions of the key set: built on four host threads (the cuckoo table dominates). */
 int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 {
@@ -145,7 +205,7 @@ int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 	/* Two-level path (15 <= k <= 31): chosen when the blocked filter at 12 bits per key is far enough out of the L2 (more than
 	 * 4.5 MiB: beyond ~3.1 M site k-mers.  Measured one level / two levels: 1.9 M keys 797 / 665, 2.6 M 715 / 650, 4.0 M
 	 * 457 / 623, 8.0 M 292 / 530, 16 M 219 / 404 Gbases/s), or forced either way with ntsm_set_kernel (4 / 2). */
-	c->run_form = c->k == NTSM_FAST_K && (c->kernel_variant == 5 || (c->kernel_variant == 0 && filter_log2_req == 0 && !c->blocks_kib_req && wants_run_form(c->k, n)));
+	c->run_form = choose_run_form(c, c->kernel_variant, filter_log2_req);
 	c->two_level = ntsm_fast_plan((uint32_t) c->k, true).m == NTSM_TWO_M && c->kernel_variant != 1 && !c->run_form &&
 		(c->kernel_variant == 4 || (c->kernel_variant == 0 && filter_log2_req == 0 && wants_two_level(n)));
 	const NtsmFastPlan plan = ntsm_fast_plan((uint32_t) c->k, c->two_level);
@@ -286,25 +346,12 @@ int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 		std::vector<uint8_t> where(n);                        /* bit q: the minimum key occurs at start offset q */
 		uint64_t entries = 0;
 		for (uint32_t i = 0; i < n; ++i) {
-			const uint64_t x = c->canon[i];
-			uint64_t rc = ~x;
-			rc = ((rc >> 2) & 0x3333333333333333ull) | ((rc & 0x3333333333333333ull) << 2);
-			rc = ((rc >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((rc & 0x0F0F0F0F0F0F0F0Full) << 4);
-			rc = __builtin_bswap64(rc) >> (64 - 2 * NTSM_FAST_K);
-			uint32_t best = 0xFFFFFFFFu;
-			uint8_t at = 0;
-			for (uint32_t q = 0; q < 8; ++q) {
-				const uint32_t sub = (uint32_t) (x >> (2 * (7 - q))) & 0xFFFFFFu, rsub = (uint32_t) (rc >> (2 * q)) & 0xFFFFFFu;
-				const uint32_t h = ntsm_run_hash24(std::min(sub, rsub));
-				if (h < best) { best = h; at = (uint8_t) (1u << q); }
-				else if (h == best) at |= (uint8_t) (1u << q);
-			}
-			hmin[i] = best;
-			where[i] = at;
-			entries += (uint64_t) __builtin_popcount(at);
+			run_minimizer(c->canon[i], &hmin[i], &where[i]);
+			entries += (uint64_t) __builtin_popcount(where[i]);
 		}
 		c->n_rentries = entries;
-		/* 16 bits per entry in steps of 64 KiB, at most 3 MiB -- the filter lives in the 4 MiB L2 beside the stream (2.5 M keys: 2 / auto
+		/* 16 bits per site k-mer (about 29 per DISTINCT signature on a set of whole windows: the k-mers of a window that share a
+		 * minimizer set the same bits) in steps of 64 KiB, at most 3 MiB -- the filter lives in the 4 MiB L2 beside the stream (2.5 M keys: 2 / auto
 		 * 2.7 / 4 MiB measure 759 / 775 / 750 Gbases/s) -- and 4 MiB beyond 2.75 M entries (5.7 M keys: 3 / 4 MiB 621 / 640; 8.3 M: 482 /
 		 * 545: by then every bit saved costs more false look-ups than the L2 misses it avoids); ntsm_set_tuning(2000000 + KiB) with
 		 * ntsm_set_kernel(5) overrides */
@@ -317,8 +364,7 @@ int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 			uint32_t *blk = &img.rblocks[(size_t) ntsm_range(ntsm_block_hash(hmin[i]), (uint32_t) c->n_rblocks) * 4];
 			for (uint32_t q = 0; q < 8; ++q) {
 				if (!((where[i] >> q) & 1u)) continue;
-				const uint32_t E = q <= 3 ? (uint32_t) (x >> (2 * (3 - q))) : (uint32_t) (x >> (2 * (7 - q)));
-				const uint32_t u = E + ntsm_rc16_word(E), um = ntsm_kmer_mix(u);
+				const uint32_t u = run_signature(x, q), um = ntsm_kmer_mix(u);
 				blk[0] |= 1u << NTSM_KBIT0(u);
 				blk[1] |= 1u << NTSM_KBIT1(um);
 				blk[2] |= 1u << NTSM_KBIT2(um);

@@ -1291,6 +1291,50 @@ def test_run_anchored_kernel_palindromes_repeats_and_short_runs(nt, tmp_path):
     ctx.close()
 
 
+def test_run_form_is_not_chosen_for_unrelated_kmers(nt):
+    """The automatic choice of the run-anchored kernel needs more than a key count in its window (1.8 M <= keys < 7 M): the site
+    set must have the cluster structure the kernel feeds on -- consecutive keys that share minimizer and anchored 16-mer, as the
+    k-mers of ntsm's 31-base windows do (tables.cpp: run_form_pays).  2 M UNRELATED random 19-mers: the automatic choice stays on
+    the minimizer-blocked kernel; forced (5) the run form still counts exactly (its filter just holds one signature per key)."""
+    rng = np.random.default_rng(99)
+    n_keys = 2_000_000
+    codes = np.unique(rng.integers(0, 1 << 38, size=n_keys + 50_000, dtype=np.int64).astype(np.uint64))
+    def rc(x):
+        r = np.zeros_like(x)
+        y = x.copy()
+        for _ in range(19):
+            r = (r << np.uint64(2)) | (np.uint64(3) - (y & np.uint64(3)))
+            y >>= np.uint64(2)
+        return r
+    canon = np.unique(np.minimum(codes, rc(codes)))[:n_keys]
+    rng.shuffle(canon)
+    assert len(canon) == n_keys
+    # reads: random bases with site k-mers (either strand) spliced in
+    n_reads, L = 40_000, 150
+    arr = rng.integers(0, 4, size=(n_reads, L), dtype=np.uint8)
+    pick = rng.integers(0, n_keys, size=n_reads)
+    for i in range(0, n_reads, 2):
+        x = int(canon[pick[i]]) if i % 4 else int(rc(canon[pick[i]:pick[i] + 1])[0])
+        off = int(rng.integers(0, L - 19))
+        arr[i, off:off + 19] = [(x >> (2 * (18 - b))) & 3 for b in range(19)]
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    flat = np.concatenate([lut[arr], np.full((n_reads, 1), ord("N"), dtype=np.uint8)], axis=1).reshape(-1)
+    ends = (np.arange(n_reads, dtype=np.uint64) * np.uint64(L + 1)) + np.uint64(L)
+    got = {}
+    for variant in (1, 0, 5):
+        ctx = nt.Context(canon)
+        ctx.set_kernel(variant)
+        st = ctx.debug_stats()
+        assert st["run_form"] == (variant == 5) and not st["two_level"], (variant, st)
+        ctx.submit(flat, ends)
+        t = ctx.sync()
+        got[variant] = (t.total_kmers, t.total_hits, ctx.counts())
+        ctx.close()
+    assert got[1][1] >= n_reads // 2 and int(got[1][2].sum()) == got[1][1]
+    for v in (0, 5):
+        assert got[v][:2] == got[1][:2] and np.array_equal(got[v][2], got[1][2]), v
+
+
 def test_tabulated_kernel_paths(nt, n10, tmp_path):
     """The tabulated k = 19 kernel is a measured negative result that lives behind -DNTSM_WITH_TAB: the default library
     refuses ntsm_set_kernel(ctx, 3); `make tab` builds ntsm_amd/libntsm_hip_tab.so with it, and tests/tab_kernel_check.py
