@@ -930,6 +930,49 @@ def test_cli_threads_over_files(nt, tmp_path):
     assert p.returncode == 0 and p.stdout == open(os.path.join(G, "expected", c["stdout"]), "rb").read()
 
 
+def test_cli_on_a_site_set_that_takes_the_run_form(nt, tmp_path):
+    """The whole CLI on a site file whose size (2.5 M k-mers: every k-mer of 96,287 windows, the upper bound of the real
+    human_sites_n10.fa) makes ntsm_create choose the run-anchored kernel: sequential submit path (-t 1), producer lanes with
+    packed and with raw-byte batches (-t 4), a .gz input, and -m (armed batches: optimistic spans through the run kernel, the
+    crossing chunk per read through the minimizer-blocked one).  stdout must be the oracle's bytes, the summary lines too."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    sp = str(tmp_path / "n10_full.fa")
+    s = nt.SynthShort(sites_seed=20241218, n_sites=96287, read_seed=77, sites_path=sp, min_keep=13, p_embed=0.3)
+    n = 150_000
+    fq = str(tmp_path / "r.fq")
+    s.write_fastq(fq, 0, n, threads=4, qual_model=1)
+    gz = fq + ".gz"
+    with open(fq, "rb") as f, gzip.open(gz, "wb", compresslevel=4) as g:
+        g.write(f.read())
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(sp)
+    fp.process_flat(bases, ends)
+    rc, want = fp.print_counts()
+    assert rc == 0 and fp.total_hits > 400_000
+    ctx = nt.Context(nt.Sites(sp).keys)
+    assert ctx.debug_stats()["run_form"] is True
+    ctx.close()
+    for args, env in ((["-t", "1", fq], {}), (["-t", "4", fq], {}), (["-t", "4", fq], {"NTSM_NO_PACK": "1"}), (["-t", "4", gz], {}), (["-t", "3", fq, gz], {})):
+        p = subprocess.run([exe, "-s", sp] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-400:]
+        if len(args) == 3:
+            assert p.stdout == want, (args, env)
+            assert ("Total k-mers Recorded: %d" % fp.total_hits).encode() in p.stderr
+        else:                                                   # both files: every count twice
+            two = OracleFP(sp)
+            two.process_flat(bases, ends)
+            two.process_flat(bases, ends)
+            assert p.stdout == two.print_counts()[1]
+    # -m: the stop read of the oracle
+    cov = 0.2
+    fm = OracleFP(sp, cov=cov)
+    fm.process_flat(bases, ends)
+    assert fm.early_term and 1000 < fm.reads_processed < n
+    p = subprocess.run([exe, "-s", sp, "-m", str(cov), fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == fm.print_counts()[1], p.stderr[-300:]
+    assert ("Total k-mers Recorded: %d" % fm.total_hits).encode() in p.stderr
+
+
 def test_cli_parallel_gzip_ingest(nt, tmp_path):
     """`reads.fq.gz` with -t N: the decoder pool inflates ONE ordinary gzip stream in parallel and the feeders parse the text
     piece-parallel (gz_stream.hpp, parallel_gz_fastq.hpp); counts.txt and the summary are the single-thread bytes -- for a
