@@ -221,6 +221,10 @@ int ntsm_debug_stats(ntsm_ctx *ctx, uint64_t out[8]);
  * lane's first error -- so an incomplete count can never be printed (the reference: exit(1) with a message,
  * src/FingerPrint.hpp:51-57, :493-499). */
 long long ntsm_debug_fail_after(int kind, long long nth);
+/* Test hook, host code only (no device needed): the run-anchored kernel's filter (ntsm_set_kernel 5, k = 19) for `keys` (canonical
+ * codes) as ntsm_create would build it, kib = its size in KiB (0 = automatic).  *n_blocks receives the number of 128-bit blocks;
+ * blocks_out, if not NULL, the image (4 words per block; call once with NULL to learn the size). */
+int ntsm_debug_run_filter(const uint64_t *keys, uint32_t n_kmers, uint32_t kib, uint32_t *blocks_out, uint64_t *n_blocks);
 /* The HIP stream (hipStream_t) ntsm_count_resident launches on. */
 void *ntsm_stream(ntsm_ctx *ctx);
 

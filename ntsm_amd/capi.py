@@ -85,6 +85,7 @@ _sig(H, "ntsm_set_armed_chunk", C.c_int, [C.c_void_p, C.c_uint64])
 _sig(H, "ntsm_stream", C.c_void_p, [C.c_void_p])
 _sig(H, "ntsm_debug_stats", C.c_int, [C.c_void_p, u64p])
 _sig(H, "ntsm_debug_fail_after", C.c_longlong, [C.c_int, C.c_longlong])
+_sig(H, "ntsm_debug_run_filter", C.c_int, [u64p, C.c_uint32, C.c_uint32, u32p, u64p])
 _sig(H, "ntsm_hash64", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_hash64_inv", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_strerror", C.c_char_p, [C.c_int])
@@ -480,6 +481,17 @@ def debug_fail_after(kind, nth):
     """ntsm_debug_fail_after: the nth call of `kind` (FAULT_*) from now on fails; 0 disarms.  Returns the calls of that kind
     seen since the previous arming."""
     return int(H.ntsm_debug_fail_after(int(kind), int(nth)))
+
+
+def debug_run_filter(keys, kib=0):
+    """The run-anchored kernel's filter for `keys` (canonical 19-mer codes), built by the host code of libntsm_hip.so without a
+    device: uint32 array [n_blocks, 4]."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    nb = C.c_uint64()
+    _chk(H.ntsm_debug_run_filter(_p(keys, u64p), len(keys), kib, None, C.byref(nb)), "ntsm_debug_run_filter")
+    out = np.zeros((nb.value, 4), dtype=np.uint32)
+    _chk(H.ntsm_debug_run_filter(_p(keys, u64p), len(keys), kib, _p(out, u32p), C.byref(nb)), "ntsm_debug_run_filter")
+    return out
 
 
 def warmup(device=0, n_streams=0):

@@ -699,6 +699,29 @@ int ntsm_set_kernel(ntsm_ctx *c, int variant)
 
 long long ntsm_debug_fail_after(int kind, long long nth) { return fault_arm(kind, nth); }
 
+/* The run-anchored kernel's filter as tables.cpp builds it, WITHOUT a device (host code only): for the CPU test that walks every
+ * site k-mer through the device's derivation (tests/test_host_cpu.py::test_run_form_filter_has_no_false_negatives). */
+int ntsm_debug_run_filter(const uint64_t *keys, uint32_t n_kmers, uint32_t kib, uint32_t *blocks_out, uint64_t *n_blocks)
+{
+	if (!keys || !n_kmers || !n_blocks) return NTSM_ERR_ARG;
+	ntsm_ctx *c = new (std::nothrow) ntsm_ctx();
+	if (!c) return NTSM_ERR_NOMEM;
+	c->k = NTSM_FAST_K;
+	c->n_kmers = n_kmers;
+	c->mask = mask_for_k(c->k);
+	c->kernel_variant = 5;
+	c->blocks_kib_req = kib;
+	c->canon.assign(keys, keys + n_kmers);
+	TableImages img;
+	const int rc = build_tables_host(c, 0, img);
+	if (rc == NTSM_OK) {
+		*n_blocks = c->n_rblocks;
+		if (blocks_out) memcpy(blocks_out, img.rblocks.data(), img.rblocks.size() * sizeof(uint32_t));
+	}
+	delete c;
+	return rc;
+}
+
 int ntsm_debug_stats(ntsm_ctx *c, uint64_t out[8])
 {
 	if (!c || !out) return NTSM_ERR_ARG;

@@ -818,6 +818,92 @@ def test_ingest_thread_counts_follow_the_cpus_granted(nt, tmp_path):
     assert len(set(seen.values())) == 1, seen                     # identical bytes whatever the grant
 
 
+def test_run_form_filter_has_no_false_negatives(nt, tmp_path):
+    """The run-anchored kernel (kernels_run.hip) looks a k-mer up only if the signature of its anchored 16-mer is in
+    the filter block of its minimizer.  Exactness therefore needs: for EVERY site k-mer, in either strand, under every alignment
+    of the window to the kernel's position counter (the order key carries position mod 16 in its low bits and decides between
+    equal 12-mers), the bits the DEVICE derives are bits the HOST set (tables.cpp sets the signature for every offset at which
+    the minimum occurs).  Walked here with numpy on the filter image the library's host code builds without a device
+    (ntsm_debug_run_filter): a 200-site set, plus the windows that stress the rule -- reverse-complement palindromes (a 12-mer
+    and its twin 8 positions on), tandem repeats of period 1 .. 7, a 12-mer repeated at distance 12 -- and three filter sizes."""
+    from ntsm_amd.capi import debug_run_filter
+    rng = np.random.default_rng(7)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rcs = lambda x: "".join(comp[c] for c in reversed(x))
+    wins = []
+    for _ in range(200):
+        wins.append("".join(rng.choice(list("ACGT"), size=31)))
+    for _ in range(120):
+        h = "".join(rng.choice(list("ACGT"), size=16))
+        wins.append((h + rcs(h))[:31] if rng.random() < 0.5 else (h[:15] + "A" + rcs(h[:15])))
+    for period in range(1, 8):
+        for _ in range(10):
+            wins.append(("".join(rng.choice(list("ACGT"), size=period)) * 31)[:31])
+    for _ in range(60):
+        a = "".join(rng.choice(list("ACGT"), size=31))
+        wins.append(a[:12] + a[:12] + a[24:])
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    fw = []
+    for w in wins:
+        for s0 in range(13):
+            x = 0
+            for ch in w[s0:s0 + 19]:
+                x = (x << 2) | code[ch]
+            fw.append(x)
+    fw = np.array(sorted(set(fw)), dtype=np.uint64)
+
+    def rc19(x):
+        r = np.zeros_like(x)
+        y = x.copy()
+        for _ in range(19):
+            r = (r << np.uint64(2)) | (np.uint64(3) - (y & np.uint64(3)))
+            y = y >> np.uint64(2)
+        return r
+
+    def rc16(w):                                             # 16-base word, first base in the top bits
+        r = np.zeros_like(w)
+        y = w.copy()
+        for _ in range(16):
+            r = (r << np.uint32(2)) | (np.uint32(3) - (y & np.uint32(3)))
+            y = y >> np.uint32(2)
+        return r
+    rc = rc19(fw)
+    canon = np.unique(np.minimum(fw, rc))
+    for kib in (0, 64, 1024):
+        blocks = debug_run_filter(canon, kib)
+        nb = np.uint64(len(blocks))
+        assert len(blocks) >= 16 and (kib == 0 or len(blocks) == kib * 64)
+        for strand in (fw, rc):                              # the read may show either strand of a site k-mer
+            srev = rc19(strand)
+            # order hashes of the eight 12-mers (start offset q = 0 .. 7): canonical code * odd mod 2^24
+            h24 = np.zeros((8, len(strand)), dtype=np.uint64)
+            for q in range(8):
+                sub = (strand >> np.uint64(2 * (7 - q))) & np.uint64(0xFFFFFF)
+                rsub = (srev >> np.uint64(2 * q)) & np.uint64(0xFFFFFF)
+                h24[q] = (np.minimum(sub, rsub) * np.uint64(0x9E3779)) & np.uint64(0xFFFFFF)
+            for align in range(16):                          # position mod 16 of the window's last base
+                # the 12-mer at start offset q ends 7 - q positions before the window's end
+                keys = np.stack([(h24[q] << np.uint64(8)) | np.uint64((align - (7 - q)) % 16) for q in range(8)])
+                win = np.argmin(keys, axis=0)                # the device's sliding minimum
+                mz = keys[win, np.arange(len(strand))]
+                o_right = (np.uint64(align) - (mz & np.uint64(15))) & np.uint64(15)
+                assert np.array_equal(o_right, (7 - win).astype(np.uint64))
+                blk = ((((mz >> np.uint64(8)) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) * nb) >> np.uint64(32)
+                q = win.astype(np.uint64)
+                # class R (four bases right of M inside the k-mer): bases q .. q+15; class L: bases q-4 .. q+11
+                shift = np.where(q <= 3, np.uint64(2) * (np.uint64(3) - np.minimum(q, np.uint64(3))), np.uint64(2) * (np.uint64(7) - q))
+                E = ((strand >> shift) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                u = (E + rc16(E)).astype(np.uint32)
+                um = (u.astype(np.uint64) * np.uint64(0x9E3779B1) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                b = blocks[blk.astype(np.int64)]
+                ok = ((b[:, 0] >> (np.uint32(31) - ((u >> np.uint32(24)) & np.uint32(31)))) & (b[:, 1] >> (np.uint32(31) - ((um >> np.uint32(24)) & np.uint32(31)))) &
+                      (b[:, 2] >> (np.uint32(31) - ((um >> np.uint32(16)) & np.uint32(31)))) & (b[:, 3] >> (np.uint32(31) - ((um >> np.uint32(8)) & np.uint32(31)))) & np.uint32(1))
+                assert ok.all(), (kib, align, int((~ok.astype(bool)).sum()))
+    # and the filter is a filter: random 19-mers mostly fail at the automatic size
+    blocks = debug_run_filter(canon, 0)
+    assert (blocks != 0).any() and (np.unpackbits(blocks.view(np.uint8)).mean() < 0.5)
+
+
 def test_early_ingest_packs_the_same_reads(nt, tmp_path):
     """early_ingest.hpp: the first input file parsed into packed chunks in ordinary memory while the sites load.  The chunks
     of a plain FASTQ and of the same reads as .gz hold the same reads as the sequential reader delivers: same number of reads
