@@ -68,6 +68,17 @@ __device__ __forceinline__ uint32_t ntsm_rc16(uint32_t w)
 	return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
 }
 
+/* hash << 8 | position.  The product is hidden from the optimiser: left alone it folds the shift into the constant and pays a
+ * full 32-bit multiply (v_mul_lo_u32, several issue slots) per position instead of v_mul_u32_u24 + v_lshl_or_b32 */
+__device__ __forceinline__ uint32_t ntsm_run_key(uint32_t canon, uint32_t pos16)
+{
+	uint32_t h = ntsm_run_hash24(canon);
+#if !defined(NTSM_RUN_FOLD_MUL)
+	asm("" : "+v"(h));
+#endif
+	return (h << 8) | pos16;
+}
+
 template <int C>
 __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kernel(const NtsmCountParams p)
 {
@@ -75,23 +86,155 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 	__shared__ __attribute__((aligned(16))) uint8_t tile[(kThreads + 1) * C];
 	__shared__ uint2 lut64[256];
 	/* A run record is 12 bytes: F (the last 16 bases as of the run's last position), W = { the 10 bases before them : 20 bits |
-	 * classes that passed : 2 (passing runs only) | spare : 2 | first position mod 16 : 4 | last position mod 16 : 4 }, K = order key
+	 * classes that passed : 2 (passing runs only) | spare : 3 | first position mod 8 : 3 | last position mod 16 : 4 }, K = order key
 	 * of the minimizer (hash << 8 | its position mod 16).  26 bases are all a run ever needs: its oldest window begins 18 + 7 bases
 	 * before its last position. */
-	__shared__ uint2 rq_all[kThreads / 64][kRunQueue];       /* run records: { F, W } */
-	__shared__ uint32_t rk_all[kThreads / 64][kRunQueue];    /*              K */
-	__shared__ uint2 cq_all[kThreads / 64][kCandQueue];      /* passing runs, same layout */
-	__shared__ uint32_t ck_all[kThreads / 64][kCandQueue];
+	__shared__ uint32_t rq_all[kThreads / 64][3][kRunQueue]; /* run records, one array per word (F, W, K): one address per push, dword stride */
+	__shared__ uint32_t cq_all[kThreads / 64][3][kCandQueue];/* passing runs, same layout */
 	__shared__ uint2 kq_all[kThreads / 64][kKmerQueue];      /* canonical codes of their k-mers, waiting for the look-up */
 	const int t = threadIdx.x;
 	const int lane = t & 63;
-	uint2 *rq = rq_all[t >> 6], *cq = cq_all[t >> 6], *kq = kq_all[t >> 6];
-	uint32_t *rk = rk_all[t >> 6], *ck = ck_all[t >> 6];
+	uint32_t *rq = rq_all[t >> 6][0], *cq = cq_all[t >> 6][0];
+	uint2 *kq = kq_all[t >> 6];
 	lut64[t] = p.lut64[t];
 	const uint32_t bshift = p.bshift, n_blocks = p.blk_map.n_blocks;
 	const unsigned long long blk_base = (unsigned long long) p.blocks;
 	const ntsm_i32x4 blk_rsrc = { (int) (uint32_t) blk_base, (int) ((uint32_t) (blk_base >> 32) | (16u << 16)), (int) (p.blk_bytes >> 4), 0x00020000 };
 	uint32_t nk_s = 0, nh = 0;
+	static_assert(C != 128, "the main loop steps through the additive row rotation");
+	const uint32_t rot0 = (uint32_t) (ntsm_run_tile_addr<C>(t + 1, 0) - (t + 1) * C);
+
+	/* The queues and the two pipelines below live across tiles: records are self-contained (bases, positions mod 16, key), so a
+	 * tile's last partial batches wait for the next tile's records instead of being flushed with half-empty waves; everything
+	 * is drained once, after the workgroup's last tile. */
+	uint32_t qn = 0, cn = 0, kn = 0;                     /* wave-uniform queue fills */
+
+	/* ---- look-up of the k-mers of passing runs, 64 at a time, two stages over consecutive calls so that no bucket load is
+	 * consumed by the call that issued it: (A) pop 64 canonical codes, issue the first bucket's load; (B, next call) compare
+	 * (bucket 2 only if bucket 1 is full -- the host inserts with that invariant), one counter update per hit ---- */
+	uint32_t l_klo = 0, l_khi = 0, l_g2 = 0;
+	unsigned long long l_b1 = 0;
+	uint4 l_ba = make_uint4(0, 0, 0, 0);
+	bool l_v = false;
+	auto lookup = [&](bool take) {
+		long long slot = -1;
+		if (l_v) {
+			if (l_ba.x == l_klo && l_ba.y == l_khi) slot = (long long) l_b1;
+			else if (l_ba.z == l_klo && l_ba.w == l_khi) slot = (long long) l_b1 + 1;
+			else if ((l_ba.x & l_ba.y) != 0xFFFFFFFFu && (l_ba.z & l_ba.w) != 0xFFFFFFFFu) {
+				const unsigned long long b2 = 2ull * (l_g2 >> bshift);
+				const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + 2ull * b2);
+				if (bb.x == l_klo && bb.y == l_khi) slot = (long long) b2;
+				else if (bb.z == l_klo && bb.w == l_khi) slot = (long long) b2 + 1;
+			}
+			if (slot >= 0) ++nh;
+		}
+		ntsm_add_hits(p, slot, lane);
+		l_v = false;
+		if (take) {
+			const uint32_t n = kn < 64 ? kn : 64;
+			kn -= n;
+			l_v = (uint32_t) lane < n;
+			if (l_v) {
+				const uint2 q = kq[kn + lane];
+				l_klo = q.x; l_khi = q.y;
+				const uint32_t fo = ntsm_fold(((unsigned long long) q.y << 32) | q.x), g1 = ntsm_h1(fo);
+				l_g2 = ntsm_h2(fo);
+				l_b1 = 2ull * (g1 >> bshift);
+				l_ba = *reinterpret_cast<const uint4 *>(p.keys + 2ull * l_b1);
+			}
+		}
+	};
+
+	/* ---- expansion of passing runs: every k-mer of the classes that passed is rebuilt (no memory access) and queued ---- */
+	auto expand = [&]() {
+		const uint32_t n = cn < 64 ? cn : 64;
+		cn -= n;
+		const bool have = (uint32_t) lane < n;
+		uint2 r = make_uint2(0, 0);
+		uint32_t rkey = 0;
+		if (have) { const uint32_t *q = cq + cn + lane; r = make_uint2(q[0], q[kCandQueue]); rkey = q[2 * kCandQueue]; }
+		const uint32_t i1 = r.y & 15u, len1 = (i1 - (r.y >> 4)) & 7u, cls = (r.y >> 10) & 3u, fh = r.y >> 12;
+		const uint32_t o1 = (i1 - rkey) & 15u, o0 = o1 - len1;
+#pragma unroll 1
+		for (uint32_t step = 0; step < 8; ++step) {
+			const uint32_t o = o0 + step;                    /* bases to the right of M in this window */
+			const bool act = have && o <= o1 && ((o >= 4u ? cls & 1u : cls & 2u) != 0u);
+			if (__builtin_amdgcn_ballot_w64(have && o <= o1) == 0ull) break;
+			const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+			if (am == 0ull) continue;
+			if (act) {
+				/* the window ends o1 - o bases before the record's newest base: its last 16 bases and the 3 before them; the reverse
+				 * complement strand is the reversed last 16 followed by the reversed first 3 */
+				const uint32_t sh = 2u * (o1 - o);
+				const uint32_t lo = __builtin_amdgcn_alignbit(fh, r.x, sh), t3 = (fh >> sh) & 63u;
+				const uint32_t rl = ntsm_rc16(lo), n3 = ~t3;
+				const uint32_t r3 = ((n3 & 3u) << 4) | (n3 & 0xCu) | ((n3 >> 4) & 3u);
+				const uint32_t a_hi = t3, a_lo = lo, b_hi = rl >> 26, b_lo = (rl << 6) | r3;
+				const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
+				const uint32_t at = kn + __builtin_amdgcn_mbcnt_hi((uint32_t) (am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) am, 0u));
+				kq[at] = make_uint2(lt ? a_lo : b_lo, lt ? a_hi : b_hi);
+			}
+			kn += (uint32_t) __popcll(am);
+			if (kn >= (uint32_t) kKmerAt) lookup(true);
+		}
+	};
+
+	/* ---- run processing, two stages over consecutive calls: (1) pop 64 records, request their blocks; (2) test ---- */
+	uint2 s_rec = make_uint2(0, 0);
+	uint32_t s_key = 0;
+	uint4 s_blk = make_uint4(0, 0, 0, 0);
+	bool s_v = false;
+	auto process = [&](bool take) {
+		/* stage 2 */
+		uint32_t cls = 0;
+		if (s_v) {
+			const uint32_t i1 = s_rec.y & 15u, len1 = (i1 - (s_rec.y >> 4)) & 7u, fh = s_rec.y >> 12;
+			const uint32_t o1 = (i1 - s_key) & 15u, o0 = o1 - len1;
+			/* E_R = M + 4 bases right ends o1 - 4 bases before the newest one; E_L = 4 bases left + M ends o1 bases before it */
+			const uint32_t wR = __builtin_amdgcn_alignbit(fh, s_rec.x, (2u * o1 - 8u) & 31u);
+			const uint32_t wL = __builtin_amdgcn_alignbit(fh, s_rec.x, 2u * o1);
+			const uint32_t uR = wR + ntsm_rc16(wR), uL = wL + ntsm_rc16(wL);
+			const uint32_t mR = ntsm_kmer_mix(uR), mL = ntsm_kmer_mix(uL);
+			/* word << field puts the tested bit (31 - field, NTSM_KBITn) into the sign position; the shifter takes the low five bits
+			 * of the selected byte, and the sign of the AND of the four is the verdict (as in kernels_mz.hip's phase C) */
+			auto passes = [&](uint32_t u, uint32_t um) -> bool {
+				uint32_t s0, s1, s2, s3;
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s0) : "v"(u), "v"(s_blk.x));
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s1) : "v"(um), "v"(s_blk.y));
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(s2) : "v"(um), "v"(s_blk.z));
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(s3) : "v"(um), "v"(s_blk.w));
+				return (int32_t) (__builtin_amdgcn_bitop3_b32(s0, s1, s2, 0x80) & s3) < 0;
+			};
+			cls = (o1 >= 4u && passes(uR, mR) ? 1u : 0u) | (o0 <= 3u && passes(uL, mL) ? 2u : 0u);
+		}
+		const unsigned long long pm = __builtin_amdgcn_ballot_w64(cls != 0u);
+		if (pm && NTSM_RUN_ABL != 2) {
+			if (cls) {
+				const uint32_t at = cn + __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
+				uint32_t *q = cq + at;
+				q[0] = s_rec.x; q[kCandQueue] = s_rec.y | (cls << 10); q[2 * kCandQueue] = s_key;
+			}
+			cn += (uint32_t) __popcll(pm);
+			if (cn >= (uint32_t) kCandAt) expand();
+		}
+		/* stage 1 */
+		s_v = false;
+		uint32_t idx = 0xFFFFFFFFu;
+		if (take) {
+			const uint32_t n = qn < 64 ? qn : 64;
+			qn -= n;
+			s_v = (uint32_t) lane < n;
+			if (s_v) {
+				const uint32_t *q = rq + qn + lane;
+				s_rec = make_uint2(q[0], q[kRunQueue]);
+				s_key = q[2 * kRunQueue];
+				idx = ntsm_range(ntsm_block_hash(s_key >> 8), n_blocks);
+			}
+		}
+		const ntsm_u32x4 bv = ntsm_struct_buffer_load_b128(blk_rsrc, (int) idx, 0, 0, 0);
+		s_blk = make_uint4(bv.x, bv.y, bv.z, bv.w);
+	};
 
 	for (unsigned long long ti = blockIdx.x; ti < p.n_tiles; ti += gridDim.x) {
 		const long long ts = p.t0 + (long long) (ti * (unsigned long long) (kThreads * C));
@@ -121,7 +264,10 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 		/* F = codes of the last 16 bases (newest lowest), Fh = the 16 before them, R = reverse complement of the last 16
 		 * (complement of the newest on top), run = 1 + valid bases since the last invalid one (window valid when run > 19) */
 		uint32_t F = 0, Fh = 0, R = 0, run = 1;
-		uint32_t sprev[8];
+		/* Sliding minimum over the eight 12-mers of a window with two v_min3_u32 per position: t3[j] = min(g[j], g[j-1], g[j-2]) and
+		 * mz[j] = min(t3[j], t3[j-3], t3[j-5]) (the three triples cover g[j-7 .. j]; g[j-5] twice).  Carried from one group of eight
+		 * positions to the next: the last two keys and the last five triples. */
+		uint32_t gp6, gp7, t3p[8];
 #define NTSM_RSTEP(e_)                                                                    \
 		{                                                                                 \
 			Fh = __builtin_amdgcn_alignbit(Fh, F, 30);                                    \
@@ -133,7 +279,7 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 		 * between different 12-mers), its position mod 16 below (says where the minimum sits; decides only between equal 12-mers).
 		 * mod 16, not 8: a 12-mer and its reverse-complement twin 8 positions on (palindromic site windows have them) would carry
 		 * the same key, and the second would take over from the first without the key -- hence the run -- changing */
-#define NTSM_RKEY(pos16_) ((ntsm_run_hash24(min(F & 0xFFFFFFu, R >> 8)) << 8) | (uint32_t) (pos16_))
+#define NTSM_RKEY(pos16_) ntsm_run_key(min(F & 0xFFFFFFu, R >> 8), (uint32_t) (pos16_))
 		{
 			const uint4 v0 = *reinterpret_cast<const uint4 *>(tile + ntsm_run_tile_addr<C>(t, C - 32));
 			const uint4 v1 = *reinterpret_cast<const uint4 *>(tile + ntsm_run_tile_addr<C>(t, C - 16));
@@ -148,199 +294,77 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 				NTSM_RSTEP(e)
 				if (i >= 25) gw[i - 24] = NTSM_RKEY(i & 15);
 			}
-			sprev[7] = gw[7];
+			gp6 = gw[6]; gp7 = gw[7];                            /* gw[8 - d] is the key d positions before the chunk */
 #pragma unroll
-			for (int i = 6; i >= 1; --i) sprev[i] = min(gw[i], sprev[i + 1]);
+			for (int i = 3; i <= 7; ++i) t3p[i] = min(min(gw[i], gw[i - 1]), gw[i - 2]);
 		}
 		uint32_t mz_prev = 0, i0 = 0;
+		uint32_t rot = rot0;                                /* where this thread's next 16 bytes sit in its (rotated) tile row */
 		unsigned long long bad_prev = ~0ull;
-		uint32_t qn = 0, cn = 0, kn = 0;                     /* wave-uniform queue fills */
-
-		/* ---- look-up of the k-mers of passing runs, 64 at a time, two stages over consecutive calls so that no bucket load is
-		 * consumed by the call that issued it: (A) pop 64 canonical codes, issue the first bucket's load; (B, next call) compare
-		 * (bucket 2 only if bucket 1 is full -- the host inserts with that invariant), one counter update per hit ---- */
-		uint32_t l_klo = 0, l_khi = 0, l_g2 = 0;
-		unsigned long long l_b1 = 0;
-		uint4 l_ba = make_uint4(0, 0, 0, 0);
-		bool l_v = false;
-		auto lookup = [&](bool take) {
-			long long slot = -1;
-			if (l_v) {
-				if (l_ba.x == l_klo && l_ba.y == l_khi) slot = (long long) l_b1;
-				else if (l_ba.z == l_klo && l_ba.w == l_khi) slot = (long long) l_b1 + 1;
-				else if ((l_ba.x & l_ba.y) != 0xFFFFFFFFu && (l_ba.z & l_ba.w) != 0xFFFFFFFFu) {
-					const unsigned long long b2 = 2ull * (l_g2 >> bshift);
-					const uint4 bb = *reinterpret_cast<const uint4 *>(p.keys + 2ull * b2);
-					if (bb.x == l_klo && bb.y == l_khi) slot = (long long) b2;
-					else if (bb.z == l_klo && bb.w == l_khi) slot = (long long) b2 + 1;
-				}
-				if (slot >= 0) ++nh;
-			}
-			ntsm_add_hits(p, slot, lane);
-			l_v = false;
-			if (take) {
-				const uint32_t n = kn < 64 ? kn : 64;
-				kn -= n;
-				l_v = (uint32_t) lane < n;
-				if (l_v) {
-					const uint2 q = kq[kn + lane];
-					l_klo = q.x; l_khi = q.y;
-					const uint32_t fo = ntsm_fold(((unsigned long long) q.y << 32) | q.x), g1 = ntsm_h1(fo);
-					l_g2 = ntsm_h2(fo);
-					l_b1 = 2ull * (g1 >> bshift);
-					l_ba = *reinterpret_cast<const uint4 *>(p.keys + 2ull * l_b1);
-				}
-			}
-		};
-
-		/* ---- expansion of passing runs: every k-mer of the classes that passed is rebuilt (no memory access) and queued ---- */
-		auto expand = [&]() {
-			const uint32_t n = cn < 64 ? cn : 64;
-			cn -= n;
-			const bool have = (uint32_t) lane < n;
-			uint2 r = make_uint2(0, 0);
-			uint32_t rkey = 0;
-			if (have) { r = cq[cn + lane]; rkey = ck[cn + lane]; }
-			const uint32_t i1 = r.y & 15u, len1 = (i1 - (r.y >> 4)) & 15u, cls = (r.y >> 10) & 3u, fh = r.y >> 12;
-			const uint32_t o1 = (i1 - rkey) & 15u, o0 = o1 - len1;
-#pragma unroll 1
-			for (uint32_t step = 0; step < 8; ++step) {
-				const uint32_t o = o0 + step;                    /* bases to the right of M in this window */
-				const bool act = have && o <= o1 && ((o >= 4u ? cls & 1u : cls & 2u) != 0u);
-				if (__builtin_amdgcn_ballot_w64(have && o <= o1) == 0ull) break;
-				const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
-				if (am == 0ull) continue;
-				if (act) {
-					/* the window ends o1 - o bases before the record's newest base: its last 16 bases and the 3 before them; the reverse
-					 * complement strand is the reversed last 16 followed by the reversed first 3 */
-					const uint32_t sh = 2u * (o1 - o);
-					const uint32_t lo = __builtin_amdgcn_alignbit(fh, r.x, sh), t3 = (fh >> sh) & 63u;
-					const uint32_t rl = ntsm_rc16(lo), n3 = ~t3;
-					const uint32_t r3 = ((n3 & 3u) << 4) | (n3 & 0xCu) | ((n3 >> 4) & 3u);
-					const uint32_t a_hi = t3, a_lo = lo, b_hi = rl >> 26, b_lo = (rl << 6) | r3;
-					const bool lt = a_hi < b_hi || (a_hi == b_hi && a_lo < b_lo);
-					const uint32_t at = kn + __builtin_amdgcn_mbcnt_hi((uint32_t) (am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) am, 0u));
-					kq[at] = make_uint2(lt ? a_lo : b_lo, lt ? a_hi : b_hi);
-				}
-				kn += (uint32_t) __popcll(am);
-				if (kn >= (uint32_t) kKmerAt) lookup(true);
-			}
-		};
-
-		/* ---- run processing, two stages over consecutive calls: (1) pop 64 records, request their blocks; (2) test ---- */
-		uint2 s_rec = make_uint2(0, 0);
-		uint32_t s_key = 0;
-		uint4 s_blk = make_uint4(0, 0, 0, 0);
-		bool s_v = false;
-		auto process = [&](bool take) {
-			/* stage 2 */
-			uint32_t cls = 0;
-			if (s_v) {
-				const uint32_t i1 = s_rec.y & 15u, len1 = (i1 - (s_rec.y >> 4)) & 15u, fh = s_rec.y >> 12;
-				const uint32_t o1 = (i1 - s_key) & 15u, o0 = o1 - len1;
-				/* E_R = M + 4 bases right ends o1 - 4 bases before the newest one; E_L = 4 bases left + M ends o1 bases before it */
-				const uint32_t wR = __builtin_amdgcn_alignbit(fh, s_rec.x, (2u * o1 - 8u) & 31u);
-				const uint32_t wL = __builtin_amdgcn_alignbit(fh, s_rec.x, 2u * o1);
-				const uint32_t uR = wR + ntsm_rc16(wR), uL = wL + ntsm_rc16(wL);
-				const uint32_t mR = ntsm_kmer_mix(uR), mL = ntsm_kmer_mix(uL);
-				/* word << field puts the tested bit (31 - field, NTSM_KBITn) into the sign position; the shifter takes the low five bits
-				 * of the selected byte, and the sign of the AND of the four is the verdict (as in kernels_mz.hip's phase C) */
-				auto passes = [&](uint32_t u, uint32_t um) -> bool {
-					uint32_t s0, s1, s2, s3;
-					asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s0) : "v"(u), "v"(s_blk.x));
-					asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s1) : "v"(um), "v"(s_blk.y));
-					asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(s2) : "v"(um), "v"(s_blk.z));
-					asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(s3) : "v"(um), "v"(s_blk.w));
-					return (int32_t) (__builtin_amdgcn_bitop3_b32(s0, s1, s2, 0x80) & s3) < 0;
-				};
-				cls = (o1 >= 4u && passes(uR, mR) ? 1u : 0u) | (o0 <= 3u && passes(uL, mL) ? 2u : 0u);
-			}
-			const unsigned long long pm = __builtin_amdgcn_ballot_w64(cls != 0u);
-			if (pm && NTSM_RUN_ABL != 2) {
-				if (cls) {
-					const uint32_t at = cn + __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
-					cq[at] = make_uint2(s_rec.x, s_rec.y | (cls << 10));
-					ck[at] = s_key;
-				}
-				cn += (uint32_t) __popcll(pm);
-				if (cn >= (uint32_t) kCandAt) expand();
-			}
-			/* stage 1 */
-			s_v = false;
-			uint32_t idx = 0xFFFFFFFFu;
-			if (take) {
-				const uint32_t n = qn < 64 ? qn : 64;
-				qn -= n;
-				s_v = (uint32_t) lane < n;
-				if (s_v) {
-					s_rec = rq[qn + lane];
-					s_key = rk[qn + lane];
-					idx = ntsm_range(ntsm_block_hash(s_key >> 8), n_blocks);
-				}
-			}
-			const ntsm_u32x4 bv = ntsm_struct_buffer_load_b128(blk_rsrc, (int) idx, 0, 0, 0);
-			s_blk = make_uint4(bv.x, bv.y, bv.z, bv.w);
-		};
-
 #pragma unroll 1
 		for (int b = 0; b < NB; ++b) {
-			const uint2 v = *reinterpret_cast<const uint2 *>(tile + ntsm_run_tile_addr<C>(t + 1, b * 8));
+			const uint2 v = *reinterpret_cast<const uint2 *>(tile + (t + 1) * C + rot + ((b & 1) << 3));
+			if (b & 1) { rot += 16; rot = rot == (uint32_t) C ? 0u : rot; }
 			const uint32_t w[2] = { v.x, v.y };
 			uint2 e[8];
 #pragma unroll
 			for (int j = 0; j < 8; ++j) e[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
-			uint32_t gg[8], pmin = 0xFFFFFFFFu;
+			uint32_t gg[8], t3[8];
 			const uint32_t pcb = (uint32_t) __builtin_amdgcn_readfirstlane((b & 1) << 3);   /* scalar: position mod 16 = pcb | j */
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
 				const uint32_t Fp = F, Fhp = Fh;                 /* the words as of the previous position: what a run that ends there is recorded with */
 				NTSM_RSTEP(e[j])
 				gg[j] = NTSM_RKEY(pcb | (uint32_t) j);
-				pmin = min(pmin, gg[j]);
-				const uint32_t mz = j + 1 <= 7 ? min(sprev[j + 1], pmin) : pmin;
+				t3[j] = min(min(gg[j], j >= 1 ? gg[j >= 1 ? j - 1 : 0] : gp7), j >= 2 ? gg[j >= 2 ? j - 2 : 0] : j == 1 ? gp7 : gp6);
+				const uint32_t mz = min(min(t3[j], j >= 3 ? t3[j >= 3 ? j - 3 : 0] : t3p[j + 5]), j >= 5 ? t3[j >= 5 ? j - 5 : 0] : t3p[j + 3]);
 				const unsigned long long bad = __builtin_amdgcn_ballot_w64(run <= (uint32_t) NTSM_FAST_K);
 				const unsigned long long chg = __builtin_amdgcn_ballot_w64(mz != mz_prev);
 				const unsigned long long endm = ~bad_prev & (chg | bad);     /* the lane's run ended with the previous position */
 				const unsigned long long startm = ~bad & (chg | bad_prev);
 				nk_s += (uint32_t) __popcll(~bad);
-				const uint32_t pos16 = pcb | (uint32_t) j;       /* position mod 16 (wave-uniform) */
 				if (endm) {
 					if (__builtin_amdgcn_inverse_ballot_w64(endm)) {
 						const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, qn));
-						rq[at] = make_uint2(Fp, (Fhp << 12) | (i0 | ((pos16 - 1u) & 15u)));   /* i0 is kept shifted: first position mod 16 << 4 */
-						rk[at] = mz_prev;
+						uint32_t *q = rq + at;
+						uint32_t w;                                  /* the last position is the previous one: a scalar */
+						asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(w) : "v"(i0), "s"((pcb + (uint32_t) j - 1u) & 15u));
+						q[0] = Fp; q[kRunQueue] = (Fhp << 12) | w;
+						q[2 * kRunQueue] = mz_prev;
 					}
 					qn += (uint32_t) __popcll(endm);
 					if (NTSM_RUN_ABL == 1) qn = 0;
 					if (qn >= 64) process(true);
 				}
-				i0 = __builtin_amdgcn_inverse_ballot_w64(startm) ? pos16 << 4 : i0;
+				i0 = __builtin_amdgcn_inverse_ballot_w64(startm) ? (uint32_t) j : i0;   /* mod 8 is enough: a run is at most 8 positions long */
 				mz_prev = mz;
 				bad_prev = bad;
 			}
-			sprev[7] = gg[7];
+			gp6 = gg[6]; gp7 = gg[7];
 #pragma unroll
-			for (int j = 6; j >= 1; --j) sprev[j] = min(gg[j], sprev[j + 1]);
+			for (int j = 3; j <= 7; ++j) t3p[j] = t3[j];
 		}
 		{   /* the chunk ends: runs that are still open are recorded with the words as they are */
 			const unsigned long long endm = ~bad_prev;
 			if (endm) {
 				if (__builtin_amdgcn_inverse_ballot_w64(endm)) {
 					const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, qn));
-					rq[at] = make_uint2(F, (Fh << 12) | (i0 | (uint32_t) ((C - 1) & 15)));
-					rk[at] = mz_prev;
+					uint32_t *q = rq + at;
+					q[0] = F; q[kRunQueue] = (Fh << 12) | ((i0 << 4) | (uint32_t) ((C - 1) & 15));
+					q[2 * kRunQueue] = mz_prev;
 				}
 				qn += (uint32_t) __popcll(endm);
+				if (qn >= 64) process(true);                    /* fewer than 64 wait when the next tile begins */
 			}
 		}
-		while (qn > 0) process(true);
-		process(false);                                     /* stage 2 of the last batch */
-		while (cn > 0) expand();
-		while (kn > 0) lookup(true);
-		lookup(false);
 #undef NTSM_RSTEP
 #undef NTSM_RKEY
 	}
+	while (qn > 0) process(true);
+	process(false);                                         /* stage 2 of the last batch */
+	while (cn > 0) expand();
+	while (kn > 0) lookup(true);
+	lookup(false);
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) nh += __shfl_down(nh, off, 64);
 	if ((t & 63) == 0) {
