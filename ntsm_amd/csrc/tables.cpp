@@ -38,11 +38,13 @@ void build_lut(uint8_t *lut)
 bool wants_two_level(uint64_t n_keys) { return (12ull * n_keys + 127) / 128 > (9ull << 15); }   /* 12 bits per key > 4.5 MiB */
 
 /* Run-anchored kernel or minimizer-blocked kernel?  Measured on 150 bp reads, site windows with all 13 k-mers kept (the clusters
- * the run form feeds on), automatic minimizer-blocked form / run form, Gbases/s: 1.56 M keys 798 / 783, 2.0 M 715 / 773, 2.5 M 672 /
- * 775, 3.4 M 619 / 753, 4.2 M 607 / 727, 5.7 M 568 / 640 (4 MiB filter), 8.3 M 522 / 545 (4 MiB); the bench set (1.54 M keys, 3 .. 13
- * k-mers kept per window) 864 / 785.  Below 1.8 M keys the one-level minimizer-blocked filter still fits the L2 with room to
- * spare and its main loop is the shorter one; from 7 M keys on the two-level form's minimizer Bloom is the better L2 resident. */
-bool wants_run_form(int k, uint64_t n_keys) { return k == NTSM_FAST_K && n_keys >= 1800000ull && n_keys < 7000000ull; }
+ * the run form feeds on), best minimizer-blocked form (one / two levels) against the run form, Gbases/s, same box (round 5, after
+ * the run kernel's queues were made to outlive their tile): 1.04 M keys 847 / 848, 1.3 M 847 / 857, 1.56 M 805 / 843, 2.0 M 715 / 831,
+ * 2.5 M 656 / 832, 3.4 M 616 / 808, 4.2 M 605 / 777, 5.7 M 563 / 649, 8.3 M 521 / 562, 10.4 M 502 / 486, 13.5 M 470 / 372; the bench
+ * set (1.54 M keys, 3 .. 13 k-mers kept per window) 862 / 866.  Below 1.8 M keys the two are level (the one-level minimizer-blocked
+ * filter still fits the L2) and the minimizer-blocked kernel stays; from 9 M keys on the two-level form's minimizer Bloom is
+ * the better L2 resident. */
+bool wants_run_form(int k, uint64_t n_keys) { return k == NTSM_FAST_K && n_keys >= 1800000ull && n_keys < 9000000ull; }
 
 uint64_t mask_for_k(int k) { return k >= 32 ? 0ull : ((1ull << (2 * k)) - 1); }   /* k = 32: see include/ntsm_hip.h */
 
@@ -351,11 +353,12 @@ int build_tables_host(ntsm_ctx *c, int filter_log2_req, TableImages &img)
 		}
 		c->n_rentries = entries;
 		/* 16 bits per site k-mer (about 29 per DISTINCT signature on a set of whole windows: the k-mers of a window that share a
-		 * minimizer set the same bits) in steps of 64 KiB, at most 3 MiB -- the filter lives in the 4 MiB L2 beside the stream (2.5 M keys: 2 / auto
-		 * 2.7 / 4 MiB measure 759 / 775 / 750 Gbases/s) -- and 4 MiB beyond 2.75 M entries (5.7 M keys: 3 / 4 MiB 621 / 640; 8.3 M: 482 /
-		 * 545: by then every bit saved costs more false look-ups than the L2 misses it avoids); ntsm_set_tuning(2000000 + KiB) with
-		 * ntsm_set_kernel(5) overrides */
-		uint64_t kib = std::max<uint64_t>(64, std::min<uint64_t>(entries < 2750000ull ? 3072 : 4096, (2 * entries / 1024 + 63) / 64 * 64));
+		 * minimizer set the same bits) in steps of 64 KiB, at most 3 MiB -- the filter lives in the 4 MiB L2 beside the stream -- and
+		 * 4 MiB beyond 5 M entries, where every bit saved costs more false look-ups than the L2 misses it avoids.  Measured,
+		 * 2 / 2.5 / 3 / 4 MiB, Gbases/s: 2.5 M keys 824 / - / 832 / 763; 3.4 M 787 / 809 / 807 / 750; 4.2 M 749 / 775 /
+		 * 777 / 735; 5.7 M 541 / 612 / 641 / 649; 8.3 M 363 / 446 / 503 / 562.  ntsm_set_tuning(2000000 + KiB) with ntsm_set_kernel(5)
+		 * overrides */
+		uint64_t kib = std::max<uint64_t>(64, std::min<uint64_t>(entries < 5000000ull ? 3072 : 4096, (2 * entries / 1024 + 63) / 64 * 64));
 		if (c->blocks_kib_req && c->kernel_variant == 5) kib = c->blocks_kib_req;
 		c->n_rblocks = kib * 64;
 		img.rblocks.assign(c->n_rblocks * 4, 0u);
