@@ -146,16 +146,34 @@ NTSM_DHD uint32_t ntsm_kmer_mix(uint32_t u) { return u * 0x9E3779B1u; }
 
 
 /* ---- k = 19 run-anchored path (kernels_run.hip) -------------------------------------------------
- * Order key of a canonical 12-mer: (code * odd) mod 2^24 -- a BIJECTION of the 24-bit code, so two different 12-mers never
- * tie -- in bits 8..31, the 12-mer's position mod 8 in the low bits (the kernel's sliding minimum thereby also says WHERE the
- * minimizer sits; the low bits only decide between occurrences of the same 12-mer).  The device returns the whole 32-bit
- * product (v_mul_u32_u24) and lets the shift by 8 drop the top byte; the host masks. */
+ * Order key of a 12-mer: a 24-bit order hash of the 12-mer, the same for both strands, in bits 8..31, the 12-mer's position
+ * mod 16 in the low bits (the kernel's sliding minimum thereby also says WHERE the minimizer sits; the low bits only decide
+ * between 12-mers of equal hash inside one window).  Two forms of the hash, chosen at build time:
+ *   NTSM_RUN_ORDER 0  (canonical code * odd) mod 2^24: a bijection of the 24-bit canonical code, different 12-mers never tie;
+ *                     five vector instructions per position (shift, mask, min, multiply, shift-or);
+ *   NTSM_RUN_ORDER 1  bits 8..31 of the 48-bit product of the two strands' codes: symmetric by commutativity, no canonical
+ *                     minimum -- three instructions (shift, v_mul_u32_u24, v_and_or_b32).  Not a bijection: different
+ *                     12-mers tie with probability 2^-24 per pair, which costs nothing -- the host sets the signature for
+ *                     EVERY offset at which the smallest hash occurs in a site k-mer, whatever 12-mer sits there. */
+#ifndef NTSM_RUN_ORDER
+#define NTSM_RUN_ORDER 1               /* measured on the 2.5 M-key set, same box: 839 (1) against 829 (0) Gbases/s; minimizer density 0.2284 against 0.2250 */
+#endif
 NTSM_DHD uint32_t ntsm_run_hash24(uint32_t canon)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return (uint32_t) __umul24(canon, 0x9E3779u);
+	return (uint32_t) __umul24(canon, 0x9E3779u);       /* the whole 32-bit product: the kernel's shift by 8 drops the top byte */
 #else
 	return (uint32_t) (((uint64_t) (canon & 0xFFFFFFu) * 0x9E3779u) & 0xFFFFFFu);
+#endif
+}
+/* host side of both forms: the 24-bit order hash of the 12-mer with forward code f12 and reverse-complement code r12 */
+static inline uint32_t ntsm_run_order24_host(uint32_t f12, uint32_t r12)
+{
+	f12 &= 0xFFFFFFu; r12 &= 0xFFFFFFu;
+#if NTSM_RUN_ORDER == 1
+	return (uint32_t) ((((uint64_t) f12 * r12) >> 8) & 0xFFFFFFu);
+#else
+	return (uint32_t) (((uint64_t) (f12 < r12 ? f12 : r12) * 0x9E3779u) & 0xFFFFFFu);
 #endif
 }
 /* reverse complement of a 16-base word (first base in the top bits) */

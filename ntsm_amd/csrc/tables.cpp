@@ -66,7 +66,7 @@ static inline void run_minimizer(uint64_t x, uint32_t *hmin, uint8_t *where)
 	uint8_t at = 0;
 	for (uint32_t q = 0; q < 8; ++q) {
 		const uint32_t sub = (uint32_t) (x >> (2 * (7 - q))) & 0xFFFFFFu, rsub = (uint32_t) (rc >> (2 * q)) & 0xFFFFFFu;
-		const uint32_t h = ntsm_run_hash24(std::min(sub, rsub));
+		const uint32_t h = ntsm_run_order24_host(sub, rsub);
 		if (h < best) { best = h; at = (uint8_t) (1u << q); }
 		else if (h == best) at |= (uint8_t) (1u << q);
 	}
