@@ -15,12 +15,14 @@
  *   Bloom is not needed, and a run is tested with at most two signature tests however many k-mers it holds.
  *
  * Structure: the main loop only rolls the words, keeps the sliding minimum (the order key carries the position of its
- * 12-mer in its low bits, so the minimum also says where M is) and, when a lane's run ends, pushes one 16-byte record
- * { last 16 bases, 16 before, key of M, first / last position } into the wave's LDS queue.  Whenever 64 records are queued the
+ * 12-mer in its low bits, so the minimum also says where M is) and, when a lane's run ends, pushes one 12-byte record
+ * { last 16 bases, the 10 before them + first / last position, key of M } into the wave's LDS queue.  Whenever 64 records are queued the
  * wave processes them with every lane busy: block index from the key, one 16-byte block load (one L2 request per run, as in
  * kernels_mz.hip), and -- one call later, when the block has arrived -- the two signature tests.  Runs that pass (true site runs
  * and ~1 % false positives) go to a second queue and are expanded 64 at a time: every k-mer of the passing class is rebuilt from
- * the record, looked up in the cuckoo table, and its counter bumped.  Exactness does not depend on the filter: it only decides
+ * the record, looked up in the cuckoo table, and its counter bumped.  The queues and the pipelines' registers outlive the tile: a
+ * record carries nothing of its tile, so partial batches wait for the next tile's records and everything is drained once, after
+ * the workgroup's last tile.  Exactness does not depend on the filter: it only decides
  * which k-mers are looked up, and it has no false negatives because a k-mer's minimizer, class and anchored 16-mer are functions
  * of the k-mer alone (the host sets the signature for every position at which the minimum order key occurs in the k-mer).
  * Not instantiated for -m mode (per-read attribution): armed batches use kernels_mz.hip's PER_READ kernels.

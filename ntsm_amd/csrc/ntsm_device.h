@@ -156,7 +156,11 @@ NTSM_DHD uint32_t ntsm_kmer_mix(uint32_t u) { return u * 0x9E3779B1u; }
  *                     12-mers tie with probability 2^-24 per pair, which costs nothing -- the host sets the signature for
  *                     EVERY offset at which the smallest hash occurs in a site k-mer, whatever 12-mer sits there. */
 #ifndef NTSM_RUN_ORDER
-#define NTSM_RUN_ORDER 1               /* measured on the 2.5 M-key set, same box: 839 (1) against 829 (0) Gbases/s; minimizer density 0.2284 against 0.2250 */
+#define NTSM_RUN_ORDER 0               /* measured, same box, form 1 against form 0: 35.8 against 38.6 vector instructions per position and minimizer
+                                        * density 0.2284 against 0.2250; but the product's small values spread less evenly over the filter blocks (mean
+                                        * false-positive rate of a signature test 0.00156 / 0.0072 / 0.0197 against 0.00131 / 0.0059 / 0.0164 at 2.5 / 5.7 /
+                                        * 8.3 M keys), so it wins 1 % up to 2.5 M keys (840 against 832 Gbases/s) and loses 2 - 8 % from 4 M on
+                                        * (4.2 M 764 / 777, 5.7 M 622 / 649, 8.3 M 518 / 562): form 0 stays */
 #endif
 NTSM_DHD uint32_t ntsm_run_hash24(uint32_t canon)
 {

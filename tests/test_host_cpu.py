@@ -875,13 +875,13 @@ def test_run_form_filter_has_no_false_negatives(nt, tmp_path):
         assert len(blocks) >= 16 and (kib == 0 or len(blocks) == kib * 64)
         for strand in (fw, rc):                              # the read may show either strand of a site k-mer
             srev = rc19(strand)
-            # order hashes of the eight 12-mers (start offset q = 0 .. 7): bits 8..31 of the product of the two strands' codes
-            # (ntsm_device.h, NTSM_RUN_ORDER 1; form 0 was (canonical code * 0x9E3779) mod 2^24)
+            # order hashes of the eight 12-mers (start offset q = 0 .. 7): (canonical code * odd) mod 2^24 (ntsm_device.h, NTSM_RUN_ORDER 0;
+            # the build-time alternative, form 1, is ((sub * rsub) >> 8) & 0xFFFFFF)
             h24 = np.zeros((8, len(strand)), dtype=np.uint64)
             for q in range(8):
                 sub = (strand >> np.uint64(2 * (7 - q))) & np.uint64(0xFFFFFF)
                 rsub = (srev >> np.uint64(2 * q)) & np.uint64(0xFFFFFF)
-                h24[q] = ((sub * rsub) >> np.uint64(8)) & np.uint64(0xFFFFFF)
+                h24[q] = (np.minimum(sub, rsub) * np.uint64(0x9E3779)) & np.uint64(0xFFFFFF)
             for align in range(16):                          # position mod 16 of the window's last base
                 # the 12-mer at start offset q ends 7 - q positions before the window's end
                 keys = np.stack([(h24[q] << np.uint64(8)) | np.uint64((align - (7 - q)) % 16) for q in range(8)])
