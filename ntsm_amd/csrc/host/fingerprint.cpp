@@ -375,6 +375,15 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 			joinPrep();
 			exit(1);
 		}
+	if (m_opt.debug_kernel >= 0)
+		for (auto *ctx : m_ctx) {
+			const int rc = ntsm_set_kernel(ctx, m_opt.debug_kernel);
+			if (rc) {
+				std::cerr << "ntsmCount: --debug-kernel " << m_opt.debug_kernel << ": " << ntsm_strerror(rc) << std::endl;
+				joinPrep();
+				exit(1);
+			}
+		}
 }
 
 FingerPrint::~FingerPrint()

@@ -28,6 +28,7 @@ struct Options {                           /* the opt:: fields ntsmCount reads (
 	double covThresh = 1.7976931348623157e308;   /* DBL_MAX: never stop */
 	bool dupes = false;
 	int device = 0;                        /* HIP device (new; the reference has no device concept) */
+	int debug_kernel = -1;                 /* --debug-kernel V (tests only): ntsm_set_kernel(ctx, V) on every context, -1 = the library's choice */
 	std::vector<int> devices;              /* -g 0,1,...: host threads (-t) are spread round-robin over these devices */
 	uint64_t batch_bytes = 64ull << 20;    /* staging capacity per slot */
 	bool phase_times = false;              /* NTSM_PHASE_TIMES: print where the wall time goes (stderr) */

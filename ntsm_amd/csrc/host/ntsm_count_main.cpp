@@ -129,6 +129,7 @@ int main(int argc, char *argv[])
 		{ "gpu", required_argument, NULL, 'g' },     { "help", no_argument, NULL, 'h' },
 		{ "version", no_argument, &OPT_VERSION, 1 }, { "verbose", no_argument, NULL, 'v' },
 		{ "debug-fault", required_argument, NULL, 1000 },      /* tests only, not in the help text: KIND:NTH -> ntsm_debug_fail_after */
+		{ "debug-kernel", required_argument, NULL, 1001 },     /* tests only: force a kernel variant (ntsm_set_kernel) */
 		{ NULL, 0, NULL, 0 } };
 	int c, option_index = 0;
 	while ((c = getopt_long(argc, argv, "s:t:vhk:m:do:g:", long_options, &option_index)) != -1) {
@@ -164,6 +165,9 @@ int main(int argc, char *argv[])
 			}
 			break;
 		}
+		case 1001:                                     /* tools/soak.py: the same inputs through every kernel form, against the oracle */
+			if (!parse(optarg, opt.debug_kernel) || opt.debug_kernel < 0) { std::cerr << "Error - Invalid parameter debug-kernel: " << optarg << std::endl; return 0; }
+			break;
 		case '?': die = true; break;
 		}
 	}

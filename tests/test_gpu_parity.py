@@ -1863,4 +1863,36 @@ def test_hot_key_throughput_guard(nt, n10):
         ctx.close()
     factor = ms["hot"] / ms["ordinary"]
     print("hot-key pass %.2f ms, ordinary pass %.2f ms, factor %.2f, %d hits per read" % (ms["hot"], ms["ordinary"], factor, hits_per_read))
-    assert factor < HOT_KEY_MAX_FACTOR, (ms, factor)
+    assert factor < HOT_KEY_MAX_FACTOR, (ms, factor)@pytest.mark.gpu
+def test_cli_through_every_kernel_form(nt, tmp_path):
+    """The CLI's hidden --debug-kernel V (ntsm_set_kernel on every context; what tools/soak.py draws from) on one small input: generic
+    (1), minimizer-blocked with one (2) and two levels (4) and run-anchored (5) print the oracle's bytes, plain and with -m (armed
+    batches, early stop, undo of the optimistic spans); a variant the build does not have (3) or a k it does not exist for (5 at
+    k = 21) is exit 1 with a message and an empty stdout."""
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    sp = str(tmp_path / "s.fa")
+    s = nt.SynthShort(sites_seed=5, n_sites=3000, read_seed=8, p_embed=0.3, sites_path=sp)
+    n = 40_000
+    fq = str(tmp_path / "r.fq")
+    s.write_fastq(fq, 0, n, threads=2)
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(sp)
+    fp.process_flat(bases, ends)
+    want = fp.print_counts()[1]
+    cov = 2.0
+    fm = OracleFP(sp, cov=cov)
+    fm.process_flat(bases, ends)
+    assert fp.total_hits > 50_000 and fm.early_term and 100 < fm.reads_processed < n
+    for form in (1, 2, 4, 5):
+        for t in ("1", "4"):
+            p = subprocess.run([exe, "-s", sp, "--debug-kernel", str(form), "-t", t, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert p.returncode == 0 and p.stdout == want, (form, t, p.stderr[-300:])
+        p = subprocess.run([exe, "-s", sp, "--debug-kernel", str(form), "-m", str(cov), fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0 and p.stdout == fm.print_counts()[1], (form, p.stderr[-300:])
+        assert ("Total k-mers Recorded: %d" % fm.total_hits).encode() in p.stderr
+    for extra in (["--debug-kernel", "3"], ["--debug-kernel", "5", "-k", "21"]):
+        p = subprocess.run([exe, "-s", sp] + extra + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 1 and p.stdout == b"" and b"--debug-kernel" in p.stderr, (extra, p.returncode, p.stderr[-300:])
+
+
+

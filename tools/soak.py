@@ -95,16 +95,21 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         env["NTSM_NO_EARLY"] = "1"
     if rng.random() < 0.3:
-        env["NTSM_SYNC_EXIT"] = "1"                            # teardown inside exit(2) instead of the CLONE_VM child
+        env["NTSM_FAST_EXIT"] = "1"                            # teardown handed to a CLONE_VM child instead of running inside exit(2) (round 5: opt-in)
+    # round 5: the same inputs through every kernel form (hidden --debug-kernel: ntsm_set_kernel on every context) -- generic (1),
+    # minimizer-blocked one level (2) / two levels (4, 15 <= k <= 31), run-anchored (5, k = 19) -- with -m, -d, early stop and undo
+    forms = [None, None, 1] + ([2] if 13 <= k <= 31 else []) + ([4] if 15 <= k <= 31 else []) + ([5, 5] if k == 19 else [])
+    form = rng.choice(forms)
+    kargs = ["--debug-kernel", str(form)] if form is not None else []
     ref = subprocess.run([ORA] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    got = subprocess.run([EXE] + args + ["-t", str(t)] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    got = subprocess.run([EXE] + args + kargs + ["-t", str(t)] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     ok = (ref.returncode == got.returncode or (ref.returncode == 134 and got.returncode == -6)) and ref.stdout == got.stdout
     if ok and ref.returncode == 0:
         ok = summary(ref.stderr) == summary(got.stderr)
     if not ok:
         fails += 1
         keep = tempfile.mkdtemp(prefix="ntsm_soak_fail_", dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
-        print("MISMATCH iteration", it, "args", args, "-t", t, "env", {k: v for k, v in env.items() if k.startswith("NTSM_")}, "rc", ref.returncode, got.returncode, "kept in", keep)
+        print("MISMATCH iteration", it, "args", args, kargs, "-t", t, "env", {k: v for k, v in env.items() if k.startswith("NTSM_")}, "rc", ref.returncode, got.returncode, "kept in", keep)
         print(got.stderr.decode()[-600:])
         for p in [sp] + files:
             subprocess.run(["cp", p, keep])
