@@ -33,9 +33,11 @@
 namespace {
 
 #ifndef NTSM_RUN_C
-#define NTSM_RUN_C 80                                  /* stream bytes per thread and tile: 80 leaves room for full-size queues at four workgroups per CU.  Measured
-                                                        * at 2.5 M keys (same box): C 128 / 3 workgroups 722 Gbases/s; C 96 with queues cut to fit four workgroups 777; C 80 with
-                                                        * full queues 789; C 64 / five workgroups 724 (the 22-base warm-up per chunk weighs more) */
+#define NTSM_RUN_C 80                                  /* stream bytes per thread and tile: 80 leaves room for full-size queues at four workgroups per CU (38.1 of
+                                                        * 40 KB).  Measured at 2.5 M keys, same box, first version of the kernel: C 128 / 3 workgroups 722 Gbases/s; C 96 with the
+                                                        * queues cut to fit four workgroups 777; C 80 789; C 64 724 (still four workgroups: the 22-base warm-up per chunk weighs
+                                                        * more).  Final version: C 80 797, C 64 761, C 64 with the candidate / k-mer queues cut to 96 entries for FIVE waves per
+                                                        * SIMD 731 */
 #endif
 #ifndef NTSM_RUN_WAVES
 #define NTSM_RUN_WAVES 4                               /* waves per SIMD the register budget is held to (LDS: 38.1 KB per workgroup at C = 80); three instead of four costs 15 % */
