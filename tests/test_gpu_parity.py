@@ -1895,4 +1895,41 @@ def test_cli_through_every_kernel_form(nt, tmp_path):
         assert p.returncode == 1 and p.stdout == b"" and b"--debug-kernel" in p.stderr, (extra, p.returncode, p.stderr[-300:])
 
 
+@pytest.mark.gpu
+def test_queues_that_outlive_their_tile(nt, tmp_path):
+    """kernels_run.hip keeps its run / candidate / k-mer queues and the registers of its two pipelines across the tiles of a
+    workgroup and drains them once, after the last tile.  With the default grid a test-sized batch gives every
+    workgroup one tile at most, so the grid is forced small here (ntsm_set_tuning(ctx, 0, grid)): 1, 3 and 64 workgroups walk
+    ~300 tiles -- one workgroup carries its queues through all of them; 3 leaves the workgroups different numbers of tiles;
+    a request larger than the tile count is clamped to one tile per workgroup (the default situation).  Counts and totals against the oracle,
+    in one batch and in two (a batch boundary inside the stream: the next launch starts with empty queues); the minimizer-blocked
+    kernel, which drains per tile, through the same grids beside it."""
+    sp = str(tmp_path / "s.fa")
+    s = nt.SynthShort(sites_seed=20241218, n_sites=4000, read_seed=31, p_embed=0.5, sites_path=sp, min_keep=13)
+    sites = nt.Sites(sp)
+    n = 40_000
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(sp)
+    fp.process_flat(bases, ends)
+    want = fp.kmers()[2]
+    assert fp.total_hits > 200_000 and len(bases) > 280 * 20480
+    for variant in (5, 2):
+        for grid in (1, 3, 64, 1 << 16):
+            ctx = nt.Context(sites.keys)
+            ctx.set_kernel(variant)
+            ctx.set_tuning(0, grid)
+            ctx.submit(bases, ends)
+            t = ctx.sync()
+            assert np.array_equal(ctx.counts(), want), (variant, grid)
+            assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases), (variant, grid)
+            cut = n // 3
+            cb = int(ends[cut - 1]) + 1
+            ctx.submit(bases[:cb], ends[:cut])
+            ctx.submit(bases[cb:], ends[cut:] - np.uint64(cb))
+            t = ctx.sync()
+            assert np.array_equal(ctx.counts(), want * np.uint64(2)), (variant, grid)
+            assert t.total_hits == 2 * fp.total_hits
+            ctx.close()
+
+
 
