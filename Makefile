@@ -34,10 +34,13 @@ HIPLIB_DEV  := $(CSRC)/kernels_generic.hip $(CSRC)/kernels_mz.hip $(CSRC)/kernel
 HIPLIB_HOST := $(CSRC)/tables.cpp $(CSRC)/runtime.cpp $(CSRC)/rccl_bind.cpp $(CSRC)/capi.cpp
 HIPLIB_HDR  := $(CSRC)/ntsm_internal.h $(CSRC)/kernels_common.h $(CSRC)/ntsm_hooks.h $(CSRC)/ntsm_device.h include/ntsm_hip.h
 HIPLIB_TAB  := $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_tab_launch.inc $(CSRC)/ntsm_tab_runtime.inc $(CSRC)/ntsm_tab_tables.inc
-# $(call hiplib,output,extra flags,object dir): every source to its own object (in parallel under -j), then one link
+# $(call hiplib,output,extra flags,object dir): every source to its own object (in parallel; stale objects removed first and every
+# compile's exit status collected, so a failed translation unit fails the recipe instead of linking an old object), then one link
 define hiplib
 	@mkdir -p $(3)
-	for f in $(HIPLIB_DEV) $(HIPLIB_HOST); do $(HIPCC) $(HIPFLAGS) -fvisibility=hidden $(2) -c $$f -o $(3)/$$(basename $$f).o & done; wait
+	rm -f $(3)/*.o
+	pids=""; for f in $(HIPLIB_DEV) $(HIPLIB_HOST); do $(HIPCC) $(HIPFLAGS) -fvisibility=hidden $(2) -c $$f -o $(3)/$$(basename $$f).o & pids="$$pids $$!"; done; \
+	rc=0; for p in $$pids; do wait $$p || rc=1; done; exit $$rc
 	$(HIPCC) $(HIPFLAGS) -shared -o $(1) $(foreach f,$(HIPLIB_DEV) $(HIPLIB_HOST),$(3)/$(notdir $(f)).o) -ldl
 endef
 

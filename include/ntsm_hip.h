@@ -225,6 +225,11 @@ long long ntsm_debug_fail_after(int kind, long long nth);
  * codes) as ntsm_create would build it, kib = its size in KiB (0 = automatic).  *n_blocks receives the number of 128-bit blocks;
  * blocks_out, if not NULL, the image (4 words per block; call once with NULL to learn the size). */
 int ntsm_debug_run_filter(const uint64_t *keys, uint32_t n_kmers, uint32_t kib, uint32_t *blocks_out, uint64_t *n_blocks);
+/* Host code only (no device needed): which kernel form ntsm_create would choose by itself for this key set -- *form = 0 the one-level
+ * minimizer-blocked kernel, 1 its two-level form, 2 the run-anchored kernel, 3 the generic kernel (k < 13, k = 32).  The choice is a
+ * function of the SET of keys (count + cluster structure estimated on a minimizer-residue sample), not of the order they are passed in:
+ * site-file order, shuffled, or m_counts' iteration order (hash order, src/FingerPrint.hpp:466) give the same answer. */
+int ntsm_debug_form_choice(const uint64_t *keys, uint32_t n_kmers, int k, int key_kind, int *form);
 /* The HIP stream (hipStream_t) ntsm_count_resident launches on. */
 void *ntsm_stream(ntsm_ctx *ctx);
 

@@ -86,6 +86,7 @@ _sig(H, "ntsm_stream", C.c_void_p, [C.c_void_p])
 _sig(H, "ntsm_debug_stats", C.c_int, [C.c_void_p, u64p])
 _sig(H, "ntsm_debug_fail_after", C.c_longlong, [C.c_int, C.c_longlong])
 _sig(H, "ntsm_debug_run_filter", C.c_int, [u64p, C.c_uint32, C.c_uint32, u32p, u64p])
+_sig(H, "ntsm_debug_form_choice", C.c_int, [u64p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int)])
 _sig(H, "ntsm_hash64", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_hash64_inv", C.c_uint64, [C.c_uint64, C.c_int])
 _sig(H, "ntsm_strerror", C.c_char_p, [C.c_int])
@@ -492,6 +493,17 @@ def debug_run_filter(keys, kib=0):
     out = np.zeros((nb.value, 4), dtype=np.uint32)
     _chk(H.ntsm_debug_run_filter(_p(keys, u64p), len(keys), kib, _p(out, u32p), C.byref(nb)), "ntsm_debug_run_filter")
     return out
+
+
+FORM_NAMES = ("one_level", "two_level", "run", "generic")
+
+
+def debug_form_choice(keys, k=19, key_kind=0):
+    """Which kernel form ntsm_create would choose for `keys` (host code only, no device): one of FORM_NAMES."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    f = C.c_int(-1)
+    _chk(H.ntsm_debug_form_choice(_p(keys, u64p), len(keys), k, key_kind, C.byref(f)), "ntsm_debug_form_choice")
+    return FORM_NAMES[f.value]
 
 
 def warmup(device=0, n_streams=0):

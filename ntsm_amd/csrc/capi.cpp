@@ -722,6 +722,25 @@ int ntsm_debug_run_filter(const uint64_t *keys, uint32_t n_kmers, uint32_t kib, 
 	return rc;
 }
 
+/* The automatic form choice without a device: what build_tables_host would decide for a fresh context (variant 0, no tuning). */
+int ntsm_debug_form_choice(const uint64_t *keys, uint32_t n_kmers, int k, int key_kind, int *form)
+{
+	if ((!keys && n_kmers) || !form || k < 1 || k > 32) return NTSM_ERR_ARG;
+	if (key_kind != NTSM_KEYS_CANONICAL && key_kind != NTSM_KEYS_HASH64) return NTSM_ERR_ARG;
+	ntsm_ctx *c = new (std::nothrow) ntsm_ctx();
+	if (!c) return NTSM_ERR_NOMEM;
+	c->k = k;
+	c->n_kmers = n_kmers;
+	c->mask = mask_for_k(k);
+	c->canon.resize(n_kmers);
+	for (uint32_t i = 0; i < n_kmers; ++i) c->canon[i] = key_kind == NTSM_KEYS_HASH64 ? ntsm_hash64_inv(keys[i], k) : keys[i];
+	const bool run = choose_run_form(c, 0, 0);
+	const bool two = !run && ntsm_fast_plan((uint32_t) k, true).m == NTSM_TWO_M && wants_two_level(n_kmers);
+	*form = ntsm_fast_plan((uint32_t) k, two).mode < 0 ? 3 : run ? 2 : two ? 1 : 0;
+	delete c;
+	return NTSM_OK;
+}
+
 int ntsm_debug_stats(ntsm_ctx *c, uint64_t out[8])
 {
 	if (!c || !out) return NTSM_ERR_ARG;

@@ -83,7 +83,7 @@ std::unique_ptr<PackedChunk> EarlyIngest::blank(uint64_t min_positions)
 			std::lock_guard<std::mutex> lk(m_mu);
 			--m_out;
 		}
-		fail("cannot allocate a " + std::to_string((want / 4 + want / 8) >> 20) + " MiB chunk for the early ingest of " + m_path);
+		fail("cannot allocate a " + std::to_string((want / 4 + want / 8) >> 20) + " MiB chunk for the early ingest of " + m_path + ": out of memory");
 		return nullptr;
 	}
 	c->pos = c->n_bases = 0;

@@ -604,7 +604,7 @@ void FingerPrint::drainEarly()
 	}
 	for (auto &th : pool) th.join();
 	if (m_early->failed()) {                                    /* reads were lost (no memory for a chunk, the file's rest unreadable): never print counts */
-		fatal("ntsmCount: " + m_early->error() + ": " + ntsm_strerror(NTSM_ERR_NOMEM));
+		fatal("ntsmCount: " + m_early->error());                /* the message names its own cause (allocation or I/O) */
 	}
 	if (m_opt.phase_times)
 		std::cerr << "[phase] " << m_opt.inputs[0] << ": early ingest (" << m_early->how() << ") parsed " << m_early->records() << " records ("

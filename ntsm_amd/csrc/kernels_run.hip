@@ -111,7 +111,8 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 	const uint32_t bshift = p.bshift, n_blocks = p.blk_map.n_blocks;
 	const unsigned long long blk_base = (unsigned long long) p.blocks;
 	const ntsm_i32x4 blk_rsrc = { (int) (uint32_t) blk_base, (int) ((uint32_t) (blk_base >> 32) | (16u << 16)), (int) (p.blk_bytes >> 4), 0x00020000 };
-	uint32_t nk_s = 0, nh = 0;
+	unsigned long long nk_s = 0;                             /* wave-uniform, lives across all tiles of the workgroup: 64 bits (a forced small grid over a large stream passes 2^32) */
+	uint32_t nh = 0;
 	uint32_t kmask = 0xFFFFFF00u;
 	asm volatile("" : "+v"(kmask));
 	static_assert(C != 128, "the main loop steps through the additive row rotation");
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 				const unsigned long long chg = __builtin_amdgcn_ballot_w64(mz != mz_prev);
 				const unsigned long long endm = ~bad_prev & (chg | bad);     /* the lane's run ended with the previous position */
 				const unsigned long long startm = ~bad & (chg | bad_prev);
-				nk_s += (uint32_t) __popcll(~bad);
+				nk_s += (unsigned long long) __popcll(~bad);
 				if (endm) {
 					if (__builtin_amdgcn_inverse_ballot_w64(endm)) {
 						const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t) (endm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) endm, qn));
@@ -378,11 +379,12 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 	while (cn > 0) expand();
 	while (kn > 0) lookup(true);
 	lookup(false);
+	unsigned long long nh_w = nh;                            /* per lane 32 bits are plenty; the sum over the wave is taken in 64 */
 #pragma unroll
-	for (int off = 32; off > 0; off >>= 1) nh += __shfl_down(nh, off, 64);
+	for (int off = 32; off > 0; off >>= 1) nh_w += __shfl_down(nh_w, off, 64);
 	if ((t & 63) == 0) {
-		if (nk_s) atomicAdd(p.totals + 0, p.sign * (unsigned long long) nk_s);
-		if (nh) atomicAdd(p.totals + 1, p.sign * (unsigned long long) nh);
+		if (nk_s) atomicAdd(p.totals + 0, p.sign * nk_s);
+		if (nh_w) atomicAdd(p.totals + 1, p.sign * nh_w);
 	}
 }
 

@@ -1334,6 +1334,37 @@ def test_run_anchored_kernel_palindromes_repeats_and_short_runs(nt, tmp_path):
     ctx.close()
 
 
+def test_run_form_is_chosen_whatever_the_order_of_the_keys(nt, tmp_path):
+    """the reference-side binding (gpuInit) hands the keys over in m_counts'
+    iteration order -- a robin_map: hash order (src/FingerPrint.hpp:466) -- as hash64 values.  The 2.5 M-key n10_full set must take
+    the run-anchored kernel in site-file order, shuffled, and in hash order with NTSM_KEYS_HASH64, and count exactly in all three
+    (dense index = position in the array the caller passed)."""
+    sp = str(tmp_path / "n10_full.fa")
+    s = nt.SynthShort(sites_seed=20241218, n_sites=96287, read_seed=77, sites_path=sp, min_keep=13, p_embed=0.3)
+    keys = nt.Sites(sp).keys
+    n = 60_000
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(sp)
+    fp.process_flat(bases, ends)
+    want = fp.kmers()[2]
+    assert fp.total_hits > 100_000 and len(want) == len(keys)
+    rng = np.random.default_rng(12)
+    perm = rng.permutation(len(keys))
+    hv = np.array([nt.hash64(int(x), 19) for x in keys], dtype=np.uint64)
+    bucket_order = np.argsort(hv & np.uint64((1 << 23) - 1), kind="stable")
+    for name, order, arr, kind in (("site order", np.arange(len(keys)), keys, 0), ("shuffled", perm, keys[perm], 0),
+                                   ("hash order, hash64 keys", bucket_order, hv[bucket_order], 1)):
+        ctx = nt.Context(arr, key_kind=kind)
+        st = ctx.debug_stats()
+        assert st["run_form"] is True and not st["two_level"], (name, st)
+        ctx.submit(bases, ends)
+        t = ctx.sync()
+        got = ctx.counts()
+        ctx.close()
+        assert (t.total_kmers, t.total_hits, t.total_bases) == (fp.total_kmers, fp.total_hits, fp.total_bases), name
+        assert np.array_equal(got, want[order]), name
+
+
 def test_run_form_is_not_chosen_for_unrelated_kmers(nt):
     """The automatic choice of the run-anchored kernel needs more than a key count in its window (1.8 M <= keys < 9 M): the site
     set must have the cluster structure the kernel feeds on -- consecutive keys that share minimizer and anchored 16-mer, as the
@@ -1863,7 +1894,10 @@ def test_hot_key_throughput_guard(nt, n10):
         ctx.close()
     factor = ms["hot"] / ms["ordinary"]
     print("hot-key pass %.2f ms, ordinary pass %.2f ms, factor %.2f, %d hits per read" % (ms["hot"], ms["ordinary"], factor, hits_per_read))
-    assert factor < HOT_KEY_MAX_FACTOR, (ms, factor)@pytest.mark.gpu
+    assert factor < HOT_KEY_MAX_FACTOR, (ms, factor)
+
+
+@pytest.mark.gpu
 def test_cli_through_every_kernel_form(nt, tmp_path):
     """The CLI's hidden --debug-kernel V (ntsm_set_kernel on every context; what tools/soak.py draws from) on one small input: generic
     (1), minimizer-blocked with one (2) and two levels (4) and run-anchored (5) print the oracle's bytes, plain and with -m (armed
