@@ -78,9 +78,25 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 void ntsm_destroy(ntsm_ctx *ctx);
 
 /* Count one batch of reads held in HOST memory (copied into pinned staging, then asynchronous
- * H2D + kernel on one of two internal streams).  The caller's buffers may be reused on return. */
+ * H2D + kernel on one of two internal streams).  The caller's buffers may be reused on return.
+ * The staging copy runs on several threads (one thread's memcpy is about half of what a PCIe Gen5 x16 link
+ * takes): ntsm_set_submit_threads sets how many, the submitting thread included (0 = automatic: min(4, CPUs of
+ * the affinity mask); 1 = the submitting thread alone). */
 int ntsm_submit(ntsm_ctx *ctx, const uint8_t *bases, uint64_t n_bytes, const uint64_t *read_end,
 		uint32_t n_reads);
+int ntsm_set_submit_threads(ntsm_ctx *ctx, int n_threads);
+/* Zero-copy variant for a caller whose reads already lie in PINNED host memory (hipHostMalloc, hipHostRegister, or
+ * ntsm_host_pin below; anything else is refused with NTSM_ERR_ARG): the H2D copy reads the caller's buffer directly, no
+ * staging copy.  Asynchronous with two batches in flight: `bases` must stay untouched until the SECOND next
+ * ntsm_submit_pinned call on this context has returned, or until ntsm_sync (an armed context, max_hits != 0, is
+ * synchronous: free on return).  read_end is ordinary memory and free on return.  This is the form of the per-read call
+ * src/FingerPrint.hpp:66-69 that needs no host-side copy at all when the parser writes into pinned memory it owns. */
+int ntsm_submit_pinned(ntsm_ctx *ctx, const uint8_t *bases, uint64_t n_bytes, const uint64_t *read_end,
+		uint32_t n_reads);
+/* hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves: pin an existing host
+ * allocation (about 0.16 ms per MiB, serialised by the driver: do it once per buffer, not per batch). */
+int ntsm_host_pin(void *p, uint64_t bytes);
+int ntsm_host_unpin(void *p);
 
 /* Zero-copy variant: parse straight into pinned staging.  acquire blocks until the slot's previous
  * batch has left the host buffer; fill at most *cap_bytes bases / *cap_reads offsets, then submit. */

@@ -56,6 +56,10 @@ H = hip_lib
 _sig(H, "ntsm_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, u64p, C.c_uint32, C.c_int, C.c_uint64])
 _sig(H, "ntsm_destroy", None, [C.c_void_p])
 _sig(H, "ntsm_submit", C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, C.c_uint32])
+_sig(H, "ntsm_submit_pinned", C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, C.c_uint32])
+_sig(H, "ntsm_set_submit_threads", C.c_int, [C.c_void_p, C.c_int])
+_sig(H, "ntsm_host_pin", C.c_int, [C.c_void_p, C.c_uint64])
+_sig(H, "ntsm_host_unpin", C.c_int, [C.c_void_p])
 _sig(H, "ntsm_staging_acquire", C.c_int, [C.c_void_p, C.POINTER(u8p), u64p, C.POINTER(u64p), u64p])
 _sig(H, "ntsm_submit_staged", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32])
 _sig(H, "ntsm_set_batch_capacity", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64])
@@ -344,6 +348,16 @@ class Context:
         read_end = np.ascontiguousarray(read_end, dtype=np.uint64)
         _chk(H.ntsm_submit(self._h, _p(bases, u8p), bases.size, _p(read_end, u64p), read_end.size), "ntsm_submit")
 
+    def submit_pinned(self, bases, read_end):
+        """ntsm_submit_pinned: `bases` must be a uint8 array inside memory pinned with host_pin (or hipHostMalloc); it must stay
+        untouched until the second next submit_pinned has returned, or until sync()."""
+        assert bases.dtype == np.uint8 and bases.flags.c_contiguous
+        read_end = np.ascontiguousarray(read_end, dtype=np.uint64)
+        _chk(H.ntsm_submit_pinned(self._h, _p(bases, u8p), bases.size, _p(read_end, u64p), read_end.size), "ntsm_submit_pinned")
+
+    def set_submit_threads(self, n):
+        _chk(H.ntsm_set_submit_threads(self._h, int(n)), "ntsm_set_submit_threads")
+
     def open_lane(self, cap_bytes=0, cap_reads=0, packed_only=False):
         """A producer lane (ntsm_lane_*): one host thread's private staging into this context."""
         return Lane(self, cap_bytes, cap_reads, packed_only)
@@ -493,6 +507,15 @@ def debug_run_filter(keys, kib=0):
     out = np.zeros((nb.value, 4), dtype=np.uint32)
     _chk(H.ntsm_debug_run_filter(_p(keys, u64p), len(keys), kib, _p(out, u32p), C.byref(nb)), "ntsm_debug_run_filter")
     return out
+
+
+def host_pin(arr):
+    """ntsm_host_pin (hipHostRegister) on a numpy array's memory; undo with host_unpin before the array is released."""
+    _chk(H.ntsm_host_pin(C.c_void_p(arr.ctypes.data), arr.nbytes), "ntsm_host_pin")
+
+
+def host_unpin(arr):
+    _chk(H.ntsm_host_unpin(C.c_void_p(arr.ctypes.data)), "ntsm_host_unpin")
 
 
 FORM_NAMES = ("one_level", "two_level", "run", "generic")

@@ -160,6 +160,7 @@ void ntsm_destroy(ntsm_ctx *c)
 		if (c->ev_b[i]) (void) hipEventDestroy(c->ev_b[i]);
 	}
 	tab_release(c);                                        /* no-op in the default build */
+	copy_pool_release(c);
 	for (auto &b : c->device_cache) (void) hipFree(b.first);
 	c->device_cache.clear();
 	void *ptrs[] = { c->d_rblocks, c->d_bloom, c->d_prefilter, c->d_lut64, c->d_blocks, c->d_filter, c->d_keys, c->d_slot_of, c->d_read_hits, c->d_totals, c->d_vec, c->d_lut };
@@ -188,8 +189,11 @@ int ntsm_staging_acquire(ntsm_ctx *c, uint8_t **bases, uint64_t *cap_bytes, uint
 	if (c->failed) return NTSM_ERR_STATE;
 	HIPCHK(hipSetDevice(c->device));
 	Slot &s = c->slot[c->next_slot];
-	if (!s.h_bases) {
+	if (!s.d_bases) {
 		int rc = alloc_slot(s, c->device, c->cap_bytes, c->cap_reads, true);
+		if (rc) return rc;
+	} else if (!s.h_bases) {                               /* the slot was made by ntsm_submit_pinned, without staging for the bases */
+		int rc = slot_add_host_bases(s);
 		if (rc) return rc;
 	}
 	int rc = wait_slot(s);
@@ -446,9 +450,85 @@ int ntsm_submit(ntsm_ctx *c, const uint8_t *bases, uint64_t n_bytes, const uint6
 	uint8_t *hb; uint64_t cb, *hr, cr;
 	rc = ntsm_staging_acquire(c, &hb, &cb, &hr, &cr);
 	if (rc) return rc;
-	memcpy(hb, bases, n_bytes);
-	memcpy(hr, read_end, (size_t) n_reads * sizeof(uint64_t));
+	/* The batch goes into the pinned slot on several threads: one thread's memcpy is half of what the link takes
+	 * (runtime.cpp: staged_copy).  The offsets are only needed where a read is attributed its hits: an armed (-m) context;
+	 * otherwise the slot keeps just the last one, which is all check_layout looks at. */
+	staged_copy(c, hb, bases, n_bytes);
+	if (c->armed) memcpy(hr, read_end, (size_t) n_reads * sizeof(uint64_t));
+	else hr[n_reads - 1] = read_end[n_reads - 1];
 	return ntsm_submit_staged(c, n_bytes, n_reads);
+}
+
+int ntsm_host_pin(void *p, uint64_t bytes)
+{
+	if (!p || !bytes) return NTSM_ERR_ARG;
+	HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+	return NTSM_OK;
+}
+
+int ntsm_host_unpin(void *p)
+{
+	if (!p) return NTSM_ERR_ARG;
+	HIPCHK(hipHostUnregister(p));
+	return NTSM_OK;
+}
+
+int ntsm_set_submit_threads(ntsm_ctx *c, int n_threads)
+{
+	if (!c || n_threads < 0 || n_threads > 64) return NTSM_ERR_ARG;
+	c->submit_threads = n_threads;
+	return NTSM_OK;
+}
+
+/* Zero-copy submit: the H2D copy reads the caller's own pinned memory.  The slot supplies the device buffer, the stream and the
+ * "done" event only; two batches may be in flight, the third call waits for the first. */
+int ntsm_submit_pinned(ntsm_ctx *c, const uint8_t *bases, uint64_t n_bytes, const uint64_t *read_end, uint32_t n_reads)
+{
+	if (!c || (n_bytes && !bases)) return NTSM_ERR_ARG;
+	if (c->failed) return NTSM_ERR_STATE;
+	int rc = check_layout(read_end, n_reads, n_bytes);
+	if (rc) return rc;
+	if (n_reads == 0) return NTSM_OK;
+	HIPCHK(hipSetDevice(c->device));
+	{
+		/* the whole batch must lie in memory the runtime knows as pinned host memory (hipHostMalloc / hipHostRegister): a DMA from
+		 * anything else would be staged by the runtime page by page behind our back, or fault */
+		hipPointerAttribute_t at_lo, at_hi;
+		const hipError_t e0 = hipPointerGetAttributes(&at_lo, bases), e1 = hipPointerGetAttributes(&at_hi, bases + n_bytes - 1);
+		if (e0 != hipSuccess || e1 != hipSuccess || at_lo.type != hipMemoryTypeHost || at_hi.type != hipMemoryTypeHost) {
+			(void) hipGetLastError();                             /* "not a registered pointer" is an answer, not a sticky error */
+			return NTSM_ERR_ARG;
+		}
+	}
+	if (n_bytes > c->cap_bytes || n_reads > c->cap_reads) {
+		uint64_t nb = std::max(c->cap_bytes, n_bytes), nr = std::max<uint64_t>(c->cap_reads, n_reads);
+		rc = ntsm_set_batch_capacity(c, nb, nr);
+		if (rc) return rc;
+	}
+	if (c->early_stop) return NTSM_OK;                    /* threshold already tripped: nothing more is counted */
+	Slot &s = c->slot[c->next_slot];
+	if (s.acquired) return NTSM_ERR_STATE;                /* a staged batch is being filled on this slot */
+	if (!s.d_bases) {
+		rc = alloc_slot(s, c->device, c->cap_bytes, c->cap_reads, true, false, nullptr, false);
+		if (rc) return rc;
+	}
+	rc = wait_slot(s);
+	if (rc) return rc;
+	c->reduced = false;
+	c->next_slot ^= 1;
+	HIPCHK(h2d_async(s.d_bases, bases, n_bytes, s.stream));
+	if (c->armed) {
+		memcpy(s.h_read_end, read_end, (size_t) n_reads * sizeof(uint64_t));
+		HIPCHK(h2d_async(s.d_read_end, s.h_read_end, n_reads * sizeof(uint64_t), s.stream));
+		return armed_batch(c, s.stream, s.d_bases, n_bytes, s.d_read_end, s.h_read_end, n_reads);   /* synchronous: the buffer is free on return */
+	}
+	rc = launch_count(c, s.stream, s.d_bases, 0, n_bytes, nullptr, 0, false, +1);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(s.done, s.stream));
+	s.busy = true;
+	c->total_bases += n_bytes - n_reads;
+	c->reads_consumed += n_reads;
+	return NTSM_OK;
 }
 
 int ntsm_count_resident(ntsm_ctx *c, const void *d_bases, uint64_t n_bytes, const void *d_read_end, uint64_t n_reads, int sign)

@@ -15,9 +15,11 @@
 #define NTSM_INTERNAL_H
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -73,6 +75,21 @@ struct Slot {
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;                 /* last use of the host buffer finished */
 	bool busy = false, acquired = false;
+};
+
+/* Helper threads of ntsm_submit's staging copy: the caller's (pageable) batch is copied into the pinned slot in `parts` pieces,
+ * piece 0 by the submitting thread, the others by persistent helpers -- one thread's memcpy (~25-30 GB/s into pinned memory) is
+ * half of what the link takes (PCIe Gen5 x16: 55-57 GB/s measured), three or four are not. */
+struct CopyPool {
+	std::vector<std::thread> helpers;
+	std::mutex mu;
+	std::condition_variable cv_work, cv_done;
+	uint8_t *dst = nullptr;
+	const uint8_t *src = nullptr;
+	uint64_t n = 0;
+	unsigned parts = 0, pending = 0;
+	uint64_t generation = 0;
+	bool quit = false;
 };
 
 #ifdef NTSM_WITH_TAB
@@ -147,6 +164,8 @@ struct ntsm_ctx {
 	int next_slot = 0;
 	uint64_t cap_bytes = 64ull << 20, cap_reads = 1ull << 20;
 	hipStream_t rstream = nullptr;             /* stream for resident batches */
+	ntsm_rt::CopyPool *copy_pool = nullptr;    /* ntsm_submit's staging copy on several threads (created on the first large batch) */
+	int submit_threads = 0;                    /* threads of that copy, the submitting one included (0 = automatic: min(4, CPUs of the affinity mask)) */
 	/* host-side totals */
 	uint64_t total_bases = 0, reads_consumed = 0;
 	bool early_stop = false, reduced = false;
@@ -226,7 +245,11 @@ void stream_put(int device, hipStream_t s);
 int build_tables(ntsm_ctx *c, int filter_log2_req, int (*before_upload)(ntsm_ctx *) = nullptr);
 hipError_t device_take(ntsm_ctx *c, void **p, uint64_t bytes);
 void device_give(ntsm_ctx *c, void *p, uint64_t bytes);
-int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device, bool packed_only = false, ntsm_ctx *cache = nullptr);
+int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device, bool packed_only = false, ntsm_ctx *cache = nullptr,
+		bool host_bases = true);
+int slot_add_host_bases(Slot &s);            /* pin the bases staging of a slot created without one (ntsm_submit_pinned came first) */
+void staged_copy(ntsm_ctx *c, uint8_t *dst, const uint8_t *src, uint64_t n);   /* ntsm_submit: the batch into the pinned slot, on submit_threads threads */
+void copy_pool_release(ntsm_ctx *c);
 void free_slot(Slot &s, ntsm_ctx *cache = nullptr);
 int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t lo, uint64_t hi,
 		const uint64_t *d_read_end, uint64_t n_reads, bool per_read, int sign);

@@ -10,7 +10,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <vector>
+
+#include <sched.h>
 
 #include "ntsm_internal.h"
 
@@ -275,13 +278,23 @@ void device_give(ntsm_ctx *c, void *p, uint64_t bytes)
 	if (p) (void) hipFree(p);
 }
 
-int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device, bool packed_only, ntsm_ctx *cache)
+int slot_add_host_bases(Slot &s)
+{
+	if (s.h_bases) return NTSM_OK;
+	s.h_bases = (uint8_t *) pool_alloc(s.h_bases_bytes);
+	if (!s.h_bases) HIPCHK(pinned_malloc((void **) &s.h_bases, s.h_bases_bytes));
+	return NTSM_OK;
+}
+
+int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool ends_on_device, bool packed_only, ntsm_ctx *cache, bool host_bases)
 {
 	s.ends_on_device = ends_on_device;
 	s.h_bases_bytes = (packed_only ? (cap_bytes & ~31ull) / 4 + (cap_bytes & ~31ull) / 8 : cap_bytes) + 64;   /* packed: 3/8 byte per position */
 	s.h_ends_bytes = cap_reads * sizeof(uint64_t);
-	s.h_bases = (uint8_t *) pool_alloc(s.h_bases_bytes);
-	if (!s.h_bases) HIPCHK(pinned_malloc((void **) &s.h_bases, s.h_bases_bytes));
+	if (host_bases) {                                       /* ntsm_submit_pinned reads the caller's own pinned memory: no staging for the bases */
+		const int rcb = slot_add_host_bases(s);
+		if (rcb) return rcb;
+	}
 	if (ends_on_device) {
 		s.h_read_end = (uint64_t *) pool_alloc(s.h_ends_bytes);
 		if (!s.h_read_end) HIPCHK(pinned_malloc((void **) &s.h_read_end, s.h_ends_bytes));
@@ -515,6 +528,79 @@ int armed_batch(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t n_
 		break;
 	}
 	return NTSM_OK;
+}
+
+/* ---- ntsm_submit's staging copy on several threads ----------------------------------------------------------------------------
+ * Pieces are cut at multiples of 4 KiB; the helpers sleep on a condition variable between batches (a batch is milliseconds of
+ * work: the wake-up is noise).  One submitting thread per context (include/ntsm_hip.h), so one job at a time. */
+static void copy_helper(CopyPool *cp, unsigned idx)
+{
+	uint64_t seen = 0;
+	for (;;) {
+		uint8_t *dst; const uint8_t *src; uint64_t n; unsigned parts;
+		{
+			std::unique_lock<std::mutex> lk(cp->mu);
+			cp->cv_work.wait(lk, [&] { return cp->quit || cp->generation != seen; });
+			if (cp->quit) return;
+			seen = cp->generation;
+			dst = cp->dst; src = cp->src; n = cp->n; parts = cp->parts;
+		}
+		if (idx < parts) {
+			const uint64_t lo = (n * idx / parts) & ~4095ull, hi = idx + 1 == parts ? n : (n * (idx + 1) / parts) & ~4095ull;
+			if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
+			std::lock_guard<std::mutex> lk(cp->mu);
+			if (--cp->pending == 0) cp->cv_done.notify_one();
+		}
+	}
+}
+
+static int auto_submit_threads()
+{
+	cpu_set_t set;
+	int cpus = 1;
+	if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+	return std::max(1, std::min(4, cpus));
+}
+
+void staged_copy(ntsm_ctx *c, uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+	const int want = c->submit_threads > 0 ? c->submit_threads : auto_submit_threads();
+	unsigned parts = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) want, n >> 22));   /* at least 4 MiB per thread */
+	if (parts <= 1) { memcpy(dst, src, n); return; }
+	if (!c->copy_pool) c->copy_pool = new (std::nothrow) CopyPool();
+	CopyPool *cp = c->copy_pool;
+	if (!cp) { memcpy(dst, src, n); return; }
+	while (cp->helpers.size() + 1 < parts) {
+		try { cp->helpers.emplace_back(copy_helper, cp, (unsigned) cp->helpers.size() + 1); }
+		catch (...) { break; }                              /* no more threads to be had: fewer pieces */
+	}
+	parts = std::min<unsigned>(parts, (unsigned) cp->helpers.size() + 1);
+	if (parts <= 1) { memcpy(dst, src, n); return; }
+	{
+		std::lock_guard<std::mutex> lk(cp->mu);
+		cp->dst = dst; cp->src = src; cp->n = n; cp->parts = parts;
+		cp->pending = parts - 1;
+		cp->generation++;
+	}
+	cp->cv_work.notify_all();
+	const uint64_t hi0 = (n / parts) & ~4095ull;
+	if (hi0) memcpy(dst, src, hi0);                          /* piece 0 on the submitting thread */
+	std::unique_lock<std::mutex> lk(cp->mu);
+	cp->cv_done.wait(lk, [&] { return cp->pending == 0; });
+}
+
+void copy_pool_release(ntsm_ctx *c)
+{
+	CopyPool *cp = c->copy_pool;
+	if (!cp) return;
+	{
+		std::lock_guard<std::mutex> lk(cp->mu);
+		cp->quit = true;
+	}
+	cp->cv_work.notify_all();
+	for (auto &t : cp->helpers) t.join();
+	delete cp;
+	c->copy_pool = nullptr;
 }
 
 int check_layout(const uint64_t *read_end, uint32_t n_reads, uint64_t n_bytes)

@@ -349,6 +349,75 @@ def test_early_stop_resident_and_batched(nt, n10):
             ctx.close()
 
 
+def test_submit_pinned_and_threaded_submit_vs_oracle(nt, n10):
+    """Round 6, the host-fed path.  ntsm_submit copies a large batch into the pinned slot on several
+    threads (pieces cut at 4 KiB; 1, 2, 3 and 4 threads, batch sizes that do and do not divide evenly) and ntsm_submit_pinned
+    reads the caller's own pinned memory with no host-side copy (two batches in flight; the caller keeps the buffer until the
+    second next call).  Both against the oracle, unarmed and armed (-m), mixed with staged batches on the same context;
+    memory the runtime does not know as pinned is refused (NTSM_ERR_ARG), nothing is counted for it."""
+    from ntsm_amd.capi import host_pin, host_unpin
+    s, sites, path = n10
+    n = 400_000                                              # 60 MB of stream: several threads' worth per batch
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(path)
+    fp.process_flat(bases, ends)
+    want = fp.kmers()[2]
+    want_t = (fp.total_kmers, fp.total_hits, fp.total_bases)
+
+    def run(ctx, how, n_batches):
+        per = -(-n // n_batches)
+        for b in range(n_batches):
+            lo, hi = b * per, min(n, (b + 1) * per)
+            getattr(ctx, how)(bases[lo * s.stride:hi * s.stride], ends[lo:hi] - np.uint64(lo * s.stride))
+        t = ctx.sync()
+        return (t.total_kmers, t.total_hits, t.total_bases), t
+
+    # threaded staging copy
+    for threads, n_batches in ((1, 2), (2, 1), (3, 3), (4, 1), (0, 2)):
+        ctx = nt.Context(sites.keys)
+        ctx.set_submit_threads(threads)
+        got, _ = run(ctx, "submit", n_batches)
+        assert got == want_t and np.array_equal(ctx.counts(), want), (threads, n_batches)
+        ctx.close()
+    # zero-copy from caller-pinned memory
+    ctx = nt.Context(sites.keys)
+    with pytest.raises(nt.NtsmError):
+        ctx.submit_pinned(bases, ends)                      # ordinary numpy memory: refused
+    assert ctx.sync().reads_consumed == 0
+    host_pin(bases)
+    try:
+        for n_batches in (1, 5):
+            ctx.reset()
+            got, _ = run(ctx, "submit_pinned", n_batches)
+            assert got == want_t and np.array_equal(ctx.counts(), want), n_batches
+        # mixed with ordinary submits on the same context (slots with and without host staging)
+        ctx.reset()
+        half = n // 2
+        ctx.submit_pinned(bases[:half * s.stride], ends[:half])
+        ctx.submit(bases[half * s.stride:], ends[half:] - np.uint64(half * s.stride))
+        ctx.submit_pinned(bases[:half * s.stride], ends[:half])
+        ctx.submit(bases[half * s.stride:], ends[half:] - np.uint64(half * s.stride))
+        t = ctx.sync()
+        assert (t.total_kmers, t.total_hits, t.total_bases) == tuple(2 * x for x in want_t)
+        assert np.array_equal(ctx.counts(), want * np.uint64(2))
+        ctx.close()
+        # armed: the stop read is the oracle's whatever the batching
+        thr = int(fp.total_hits * 0.4)
+        fpm = OracleFP(path, cov=2.0 * (thr + 0.5) / len(sites.keys))
+        assert fpm.max_hits == thr
+        fpm.process_flat(bases, ends)
+        assert fpm.early_term
+        for n_batches in (1, 4):
+            ctx = nt.Context(sites.keys, max_hits=thr)
+            _, t = run(ctx, "submit_pinned", n_batches)
+            assert t.early_stop == 1 and t.reads_consumed == fpm.reads_processed
+            assert (t.total_kmers, t.total_hits, t.total_bases) == (fpm.total_kmers, fpm.total_hits, fpm.total_bases)
+            assert np.array_equal(ctx.counts(), fpm.kmers()[2])
+            ctx.close()
+    finally:
+        host_unpin(bases)
+
+
 def test_duplicate_keys_rejected(nt):
     with pytest.raises(nt.NtsmError):
         nt.Context(np.array([5, 9, 5], dtype=np.uint64), k=19)
