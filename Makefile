@@ -18,7 +18,7 @@ HOSTSRC  := $(HOST)/seq_reader.cpp $(HOST)/site_set.cpp $(HOST)/report.cpp $(HOS
             $(HOST)/inflate.cpp $(HOST)/inflate_spec.cpp $(HOST)/gz_stream.cpp $(HOST)/gz_parallel.cpp $(HOST)/crc32_fast.cpp $(HOST)/pack2.cpp
 HOSTHDR  := $(wildcard $(HOST)/*.hpp) include/ntsm_host.h include/ntsm_hip.h
 
-all: oracle_all build/ntsm_synth build/gather_bench build/ntsm_feed_bench ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount ntsm_amd/libntsm_eval_hip.so build/ntsmEval
+all: oracle_all build/ntsm_synth build/gather_bench build/ntsm_feed_bench build/ubench/inflate_wave ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount ntsm_amd/libntsm_eval_hip.so build/ntsmEval
 
 # host-only pieces (reader, site loader, report formatting): no HIP dependency
 ntsm_amd/libntsm_host.so: $(HOSTSRC) $(HOST)/early_ingest.cpp $(HOST)/host_capi.cpp $(HOSTHDR)
@@ -96,6 +96,11 @@ build/ntsm_feed_bench: tools/feed_bench.cpp $(HOST)/pack2.cpp $(HOSTHDR) include
 	@mkdir -p build
 	$(HIPCC) -O3 -std=c++17 -Wall -Wextra -o $@ tools/feed_bench.cpp $(HOST)/pack2.cpp -Lntsm_amd -lntsm_hip -lntsm_host -lntsm_synth -pthread \
 	    -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
+
+# gate for a device-side inflate of FASTQ .gz: one wave per chunk of a deflate stream
+build/ubench/inflate_wave: tools/ubench/inflate_wave.hip $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
+	@mkdir -p build/ubench
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -Wall -Wextra -o $@ tools/ubench/inflate_wave.hip $(CSRC)/synth_host.cpp -lz -pthread
 
 build/gather_bench: tools/gather_bench.hip
 	@mkdir -p build

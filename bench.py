@@ -15,7 +15,7 @@ line -- never an N = 1 line for an N > 1 request.
 Prints ONE JSON line (rank 0).  `roofline` is for the count kernel: algorithmic bytes = (L + 8) / L per base
  over the HIP-event launch time; `cpu_baseline` is the reference's CPU path timed on a bounded sample of
 the same reads.  At N = 1 the line also carries `other_configs`: BASELINE.json configs[2] (long reads, with and
-without -m 10), configs[4] (1 M sites) and the file -> counts.txt path through build/ntsmCount, each with its own
+without -m 10), configs[4] (1 M sites), the host-fed path on its PCIe roofline (`feed`) and the file -> counts.txt path through build/ntsmCount, each with its own
 correctness check; `n10_full` is the same measurement at the upper bound of the real sites file's size
 (2.5 M site k-mers).
 """
@@ -32,9 +32,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r05_traffic.json"          # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
-STRESS_TRAFFIC_FILE = "r05_stress_traffic.json"
-N10_FULL_TRAFFIC_FILE = "r05_n10_full_traffic.json"
+TRAFFIC_FILE = "r06_traffic.json"          # written by tools/make_traffic.py from the PMC passes of tools/profile.sh
+STRESS_TRAFFIC_FILE = "r06_stress_traffic.json"
+N10_FULL_TRAFFIC_FILE = "r06_n10_full_traffic.json"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 SITES_SEED, N_SITES, READ_SEED, READ_LEN, K = 20241218, 96287, 7, 150, 19
 
@@ -52,7 +52,8 @@ def parse_args(argv=None):
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (minimizer-blocked kernel for k=19), 1 generic")
     ap.add_argument("--no-check", action="store_true", help="skip the correctness check of the timed result")
-    ap.add_argument("--other-configs", default="long,stress,n10_full,e2e",
+    ap.add_argument("--feed-reads", type=float, default=2e7, help="pre-parsed reads (host memory) of the host-fed legs: 2e7 = 3.02 GB of stream")
+    ap.add_argument("--other-configs", default="long,stress,n10_full,feed,e2e",
                     help="comma list of the secondary single-GPU measurements appended at N = 1 ('' or 'none': skip)")
     ap.add_argument("--long-reads", type=float, default=5e6)
     ap.add_argument("--stress-sites", type=float, default=1e6)
@@ -310,6 +311,11 @@ def config_sites(nt, torch, dev, local, tmp, label, what, sites_seed, n_sites, m
            "reads": n_reads, "reads_asked": asked, "site_kmers": len(sites.keys), "kernel_ms": ms, "gbases_per_s": bases / ms / 1e6,
            "roofline_frac": bases * (READ_LEN + 8) / READ_LEN / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel_form": "run-anchored" if run_form else "two-level" if two_level else "one-level",
            "hits_per_pass": t.total_hits // reps, "site_gen_and_load_s": t_sites, "create_s": t_create,
+           # ONE traffic figure per leg, the same definition as the headline's roofline.traffic: bytes through the L2's memory-side
+           # port (128 x RDREQ_128B + 64 x RDREQ_64B + 32 x other reads + write requests), per launch, from the PMC passes
+           "traffic": tj["traffic_bytes_per_base"] * bases if tj and tj.get("traffic_bytes_per_base") else None,
+           "traffic_bytes_per_base_from_pmc": tj.get("traffic_bytes_per_base") if tj else None,
+           "traffic_over_algorithmic": tj.get("traffic_over_algorithmic") if tj else None,
            "fabric_read_requests_per_base_from_pmc": tj.get("fabric_read_requests_per_base") if tj else None,
            "l2_requests_per_base_from_pmc": tj.get("l2_requests_per_base") if tj else None,
            "l2_misses_per_base_from_pmc": tj.get("l2_misses_per_base") if tj else None,
@@ -618,6 +624,28 @@ def config_e2e(nt, torch, dev, local, synth, sites, sites_path, args, tmp, singl
     return out, gz_out, single_out
 
 
+def config_feed(local, args):
+    """The HOST-FED path (what a caller of the C ABI that replaces the reference's read loop, src/FingerPrint.hpp:66-69, gets):
+    pre-parsed reads in host memory pushed through every submit form of include/ntsm_hip.h by build/ntsm_feed_bench
+    (tools/feed_bench.cpp; its own process: this one holds torch's context), each leg against a pinned hipMemcpyAsync ceiling
+    measured in the same process, each leg's counts checked against the resident path."""
+    exe = os.path.join(ROOT, "build", "ntsm_feed_bench")
+    p = subprocess.run([exe, "--reads", "%d" % int(args.feed_reads), "--device", str(local), "--lanes", "1,4,16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if p.returncode != 0:
+        if b"COUNTS DIFFER" in p.stderr:
+            raise AssertionError("feed: a host-fed leg's counts differ from the resident path's: " + p.stderr.decode()[-600:])
+        raise RuntimeError("ntsm_feed_bench failed: " + p.stderr.decode()[-400:])
+    out = json.loads(p.stdout.decode().strip().split("\n")[-1])
+    assert out["all_counts_equal_resident_path"] is True
+    out["roofline"] = {"bound": "pcie", "peak_GBps_measured": out["h2d_ceiling"]["GBps"], "peak_GBps_nominal": 64.0,
+                       "achieved_GBps": {k: v["link_GBps"] for k, v in out["legs"].items()},
+                       "frac_of_measured_ceiling": {k: v["frac_of_h2d_ceiling"] for k, v in out["legs"].items()},
+                       "note": "bytes handed to the H2D copies per second; raw-byte legs move 151/150 byte per base, packed lanes 3/8 byte per position "
+                               "(152 positions per 150 bp read) and are bound by the lane threads' packing, not by the link"}
+    out["host"] = host_info()
+    return out
+
+
 def run_rank(args):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -772,12 +800,15 @@ def run_rank(args):
         bytes_per_base = (READ_LEN + 8) / READ_LEN
         achieved = bases_per_step * bytes_per_base / launch_s / 1e9
         tj, traffic_note = pmc_constants(TRAFFIC_FILE, args.kernel in (0, 2))
-        traffic = valu_busy = l2_frac = None
+        traffic = valu_busy = l2_frac = traffic_over_alg = None
         if tj:
-            traffic = tj["traffic_bytes_per_base"] * bases_per_step
+            if tj.get("traffic_bytes_per_base"):
+                traffic = tj["traffic_bytes_per_base"] * bases_per_step
+                traffic_over_alg = tj.get("traffic_over_algorithmic")
             valu_busy, l2_frac = tj.get("valu_busy_frac"), tj.get("l2_request_rate_frac_of_cap")
-            traffic_note = ("fabric-side bytes/launch from FETCH_SIZE+WRITE_SIZE (%s): L2 misses of filter/table "
-                            "served by the Infinity Cache + the stream; not HBM re-reads" % traffic_note)
+            traffic_note = ("bytes/launch through the L2's memory-side port: 128 x TCC_EA0_RDREQ_128B + 64 x RDREQ_64B + 32 x other reads + write requests "
+                            "(%s; separate --pmc passes): the stream once + the filter / key-table lines that miss the L2 and are served by the "
+                            "Infinity Cache; rocprofv3 on gfx950 has no HBM-side counter (profiles/r05_counters/)" % traffic_note)
         out = {
             "metric": "bases/s (and reads/s) through ntsmCount, 150 bp reads vs human_sites_n10.fa",   # BASELINE.json's metric
             "value": value, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -794,7 +825,7 @@ def run_rank(args):
                        "launched_by": "bench.py --gpus N (self-spawned ranks)" if os.environ.get("NTSM_BENCH_SELF_LAUNCHED") else
                                       ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_over_algorithmic": traffic_over_alg,
                          "traffic_note": traffic_note,
                          "achieved_stream_only_GBs": bases_per_step * (READ_LEN + 1) / READ_LEN / launch_s / 1e9,
                          "kernel": {0: "ntsm_count_mz_kernel", 2: "ntsm_count_mz_kernel"}.get(args.kernel, "ntsm_count_kernel"),
@@ -858,6 +889,8 @@ def run_rank(args):
                         other["stress"] = config_stress(ntsm_amd, torch, dev, local, args, tmp)
                     elif name == "n10_full":
                         other["n10_full"] = config_n10_full(ntsm_amd, torch, dev, local, args, tmp)
+                    elif name == "feed":
+                        other["feed"] = config_feed(local, args)
                     elif name == "e2e":
                         other["e2e_cli"], other["e2e_cli_gz"], other["e2e_cli_gz_single"] = config_e2e(ntsm_amd, torch, dev, local, synth, sites, sites_path, args, tmp, single)
                     else:

@@ -80,7 +80,7 @@ void ntsm_destroy(ntsm_ctx *ctx);
 /* Count one batch of reads held in HOST memory (copied into pinned staging, then asynchronous
  * H2D + kernel on one of two internal streams).  The caller's buffers may be reused on return.
  * The staging copy runs on several threads (one thread's memcpy is about half of what a PCIe Gen5 x16 link
- * takes): ntsm_set_submit_threads sets how many, the submitting thread included (0 = automatic: min(4, CPUs of
+ * takes): ntsm_set_submit_threads sets how many, the submitting thread included (0 = automatic: min(6, CPUs of
  * the affinity mask); 1 = the submitting thread alone). */
 int ntsm_submit(ntsm_ctx *ctx, const uint8_t *bases, uint64_t n_bytes, const uint64_t *read_end,
 		uint32_t n_reads);

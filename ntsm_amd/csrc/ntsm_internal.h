@@ -165,7 +165,7 @@ struct ntsm_ctx {
 	uint64_t cap_bytes = 64ull << 20, cap_reads = 1ull << 20;
 	hipStream_t rstream = nullptr;             /* stream for resident batches */
 	ntsm_rt::CopyPool *copy_pool = nullptr;    /* ntsm_submit's staging copy on several threads (created on the first large batch) */
-	int submit_threads = 0;                    /* threads of that copy, the submitting one included (0 = automatic: min(4, CPUs of the affinity mask)) */
+	int submit_threads = 0;                    /* threads of that copy, the submitting one included (0 = automatic: min(6, CPUs of the affinity mask)) */
 	/* host-side totals */
 	uint64_t total_bases = 0, reads_consumed = 0;
 	bool early_stop = false, reduced = false;

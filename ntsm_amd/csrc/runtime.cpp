@@ -309,6 +309,8 @@ int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool
 		s.stream = stream_get(device);
 		if (!s.stream) return NTSM_ERR_HIP;
 	}
+	/* (events with hipEventBlockingSync -- waiting threads sleep instead of spinning -- were measured on the 16-CPU pod: no gain for
+	 * 16 packed lanes, 68.5 vs 67.3 Gbases/s, and ntsm_submit 25 % slower, 39.9 vs 53.4 GB/s: NOTEBOOK.md round 6) */
 	if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
 	s.busy = false;
 	s.acquired = false;
@@ -559,7 +561,7 @@ static int auto_submit_threads()
 	cpu_set_t set;
 	int cpus = 1;
 	if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
-	return std::max(1, std::min(4, cpus));
+	return std::max(1, std::min(6, cpus));                  /* 2 / 3 / 4 / 6 / 8 threads: 77 / 91 / 86 / 94 / 93 % of the pinned-copy ceiling (tools/feed_bench.cpp) */
 }
 
 void staged_copy(ntsm_ctx *c, uint8_t *dst, const uint8_t *src, uint64_t n)

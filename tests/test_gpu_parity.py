@@ -1809,7 +1809,7 @@ def test_bench_contract_line(nt):
     scaled: value = bases / time, frac = achieved / peak."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2e6", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000",
                         "--long-reads", "2e4", "--stress-sites", "2e4", "--stress-reads", "1e6", "--n10-full-sites", "2e4", "--n10-full-reads", "1e6",
-                        "--e2e-reads", "2e5", "--e2e-gz-single-reads", "5e4", "--e2e-threads", "4"],
+                        "--e2e-reads", "2e5", "--e2e-gz-single-reads", "5e4", "--e2e-threads", "4", "--feed-reads", "2e6"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()[-1500:]
     lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
@@ -1832,7 +1832,16 @@ def test_bench_contract_line(nt):
     assert d["check"]["equals_generic_kernel_sum_of_pieces_below_2GiB"] is True
     # the secondary configurations ride on the same line, each with its own check (configs[2], configs[4], CLI)
     o = d["other_configs"]
-    assert set(o) == {"long", "stress", "n10_full", "e2e_cli", "e2e_cli_gz", "e2e_cli_gz_single"} and not any("error" in v for v in o.values()), o
+    assert set(o) == {"long", "stress", "n10_full", "feed", "e2e_cli", "e2e_cli_gz", "e2e_cli_gz_single"} and not any("error" in v for v in o.values()), o
+    # the host-fed path on its own (PCIe) roofline: every submit form of the C ABI against a pinned-copy ceiling measured in the
+    # same process, every leg's counts equal to the resident path's
+    f = o["feed"]
+    assert f["all_counts_equal_resident_path"] is True and f["reads"] == 2000000 and f["h2d_ceiling"]["GBps"] > 1
+    assert {"submit_1thread", "submit", "staged", "submit_pinned", "lanes_raw_1", "lanes_raw_4", "lanes_raw_16", "lanes_packed_1", "lanes_packed_4", "lanes_packed_16"} <= set(f["legs"])
+    for name, leg in f["legs"].items():
+        assert leg["counts_equal_resident_path"] is True and leg["gbases_per_s"] > 0 and leg["link_GBps"] > 0, name
+        assert abs(leg["frac_of_h2d_ceiling"] - leg["link_GBps"] / f["h2d_ceiling"]["GBps"]) < 2e-3, name
+    assert f["roofline"]["bound"] == "pcie" and f["roofline"]["peak_GBps_nominal"] == 64.0
     assert o["e2e_cli_gz"]["check"]["counts_txt_equals_plain_fastq_run"] and o["e2e_cli_gz"]["wall_s"] > 0
     # the CLI legs: realistic quality lines, an ordinary single-threaded gzip stream beside the pigz-style one, both exit
     # modes reported (wall_s = the default, synchronous one), the host's CPU grant stated

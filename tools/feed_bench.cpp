@@ -101,7 +101,9 @@ void jadd(const char *fmt, ...)
 
 int main(int argc, char **argv)
 {
-	uint64_t n_reads = 20000000ull, batch_mib = 64, sites_seed = 20241218ull, read_seed = 7;
+	uint64_t n_reads = 20000000ull, batch_mib = 64, lane_batch_mib = 8, sites_seed = 20241218ull, read_seed = 7;
+	std::string sweep_arg = "";
+
 	uint32_t n_sites = 96287, read_len = 150;
 	int device = 0, reps = 2;
 	std::string lanes_arg = "1,4,16", legs_arg = "all";
@@ -109,6 +111,8 @@ int main(int argc, char **argv)
 		const std::string k = argv[i], v = argv[i + 1];
 		if (k == "--reads") n_reads = (uint64_t) strtod(v.c_str(), nullptr);
 		else if (k == "--batch-mib") batch_mib = strtoull(v.c_str(), nullptr, 10);
+		else if (k == "--lane-batch-mib") lane_batch_mib = strtoull(v.c_str(), nullptr, 10);
+		else if (k == "--submit-threads") sweep_arg = v;            /* comma list: one extra `submit` leg per thread count */
 		else if (k == "--device") device = atoi(v.c_str());
 		else if (k == "--reps") reps = std::max(1, atoi(v.c_str()));
 		else if (k == "--lanes") lanes_arg = v;
@@ -167,6 +171,7 @@ int main(int argc, char **argv)
 
 	jadd("{\"workload\": \"%llu pre-parsed synthetic 150 bp reads (%.2f GB flat stream) in host memory, hs_n10_like sites (%u site 19-mers), batches of %llu MiB\"",
 		(unsigned long long) n_reads, n_bytes / 1e9, n_kmers, (unsigned long long) batch_mib);
+	jadd(", \"lane_batch_MiB\": %llu", (unsigned long long) lane_batch_mib);
 	jadd(", \"reads\": %llu, \"bases\": %llu, \"stream_bytes\": %llu, \"batch_bytes\": %llu, \"reps\": %d, \"cpus_in_affinity_mask\": %u, \"generate_s\": %.3f",
 		(unsigned long long) n_reads, (unsigned long long) n_bases, (unsigned long long) n_bytes, (unsigned long long) (batch_reads * stride), reps, cpus, gen_s);
 
@@ -221,6 +226,9 @@ int main(int argc, char **argv)
 	/* run `body` reps times between ntsm_reset and the final sync; link_bytes = what one repetition hands to the H2D copies */
 	auto leg = [&](const std::string &name, uint64_t link_bytes, const char *bound_by, const std::function<void()> &body, const std::function<void()> &before = nullptr,
 			const std::function<void()> &after = nullptr, const std::function<void()> &finish_timed = nullptr) {
+		/* both staging slots exist before the clock starts (pinning 2 x 64 MiB is 20-30 ms, once per context, not per batch) */
+		NTOK(ntsm_submit(ctx, stream, stride, rel_end.data(), 1));
+		NTOK(ntsm_submit(ctx, stream, stride, rel_end.data(), 1));
 		NTOK(ntsm_reset(ctx));
 		if (before) before();
 		const double t0 = now_s();
@@ -257,6 +265,19 @@ int main(int argc, char **argv)
 				NTOK(ntsm_submit(ctx, stream + r0 * stride, nr * stride, rel_end.data(), (uint32_t) nr));
 			}
 		});
+	for (size_t p = 0; p < sweep_arg.size();) {
+		size_t q = sweep_arg.find(',', p);
+		if (q == std::string::npos) q = sweep_arg.size();
+		const int th = atoi(sweep_arg.substr(p, q - p).c_str());
+		p = q + 1;
+		if (th < 1) continue;
+		leg("submit_" + std::to_string(th) + "threads", n_bytes, "staging copy on that many threads", [&] {
+			for (uint64_t b = 0; b < n_batches; ++b) {
+				uint64_t r0, nr; batch_of(b, &r0, &nr);
+				NTOK(ntsm_submit(ctx, stream + r0 * stride, nr * stride, rel_end.data(), (uint32_t) nr));
+			}
+		}, [&] { NTOK(ntsm_set_submit_threads(ctx, th)); }, [&] { NTOK(ntsm_set_submit_threads(ctx, 0)); });
+	}
 	if (want("staged")) {
 		const unsigned fill_threads = std::max(1u, std::min(4u, cpus));
 		leg("staged", n_bytes, "the link (the caller fills the pinned slot itself, here on several threads)", [&] {
@@ -290,7 +311,8 @@ int main(int argc, char **argv)
 			if (!want(name.c_str()) && !want(packed ? "lanes_packed" : "lanes_raw")) continue;
 			std::vector<ntsm_lane *> lanes(T, nullptr);
 			/* positions per packed batch: every read starts at a multiple of 8 -> 152 positions per 150 bp read */
-			const uint64_t cap_pos = ((batch_mib << 20) + 31) & ~31ull;
+			const uint64_t cap_pos = ((lane_batch_mib << 20) + 31) & ~31ull;
+			const uint64_t lane_reads = std::max<uint64_t>(1, (lane_batch_mib << 20) / stride);
 			uint64_t link = 0;
 			if (packed) link = (n_reads * 152 + 31) / 32 * 12;          /* 3/8 byte per position */
 			else link = n_bytes;
@@ -317,7 +339,7 @@ int main(int argc, char **argv)
 								if (ntsm_lane_acquire(ln, &hb, &cb, &hr, &cr)) { err = 1; return; }
 								const uint64_t nr = std::min<uint64_t>(std::min(cb / stride, cr), r1 - r);
 								memcpy(hb, stream + r * stride, nr * stride);
-								memcpy(hr, rel_end.data(), nr * sizeof(uint64_t));
+								hr[nr - 1] = rel_end[nr - 1];                    /* lanes are never armed: only the last offset is looked at */
 								if (ntsm_lane_submit(ln, nr * stride, (uint32_t) nr)) { err = 1; return; }
 								r += nr;
 							}
@@ -328,7 +350,7 @@ int main(int argc, char **argv)
 				[&] {
 					for (unsigned t = 0; t < T; ++t) {
 						if (packed) NTOK(ntsm_lane_open_packed(ctx, cap_pos, &lanes[t]));
-						else NTOK(ntsm_lane_open(ctx, batch_reads * stride, batch_reads, &lanes[t]));
+						else NTOK(ntsm_lane_open(ctx, lane_reads * stride, lane_reads, &lanes[t]));
 					}
 				},
 				nullptr,

@@ -24,11 +24,30 @@ def kernel_source_sha16():
         h.update(open(os.path.join(ROOT, f), "rb").read())
     mk = open(os.path.join(ROOT, "Makefile")).read().split("\n")
     for i, line in enumerate(mk):
-        if line.startswith("HIPFLAGS") or line.startswith("ntsm_amd/libntsm_hip.so:") or line.startswith("\tfor f in $(HIPLIB_DEV)") or line.startswith("\t$(HIPCC) $(HIPFLAGS) -shared -o $(1)"):
+        if line.startswith("HIPFLAGS") or line.startswith("ntsm_amd/libntsm_hip.so:") or line.startswith("\tpids=\"\"; for f in $(HIPLIB_DEV)") or line.startswith("\t$(HIPCC) $(HIPFLAGS) -shared -o $(1)"):
             h.update(line.encode())
             if line.startswith("ntsm_amd/libntsm_hip.so:") and i + 1 < len(mk):
                 h.update(mk[i + 1].encode())
     return h.hexdigest()[:16]
+
+
+def memory_side_bytes(c):
+    """Bytes that crossed the L2's memory-side port per launch, from the fabric ("EA") request counters -- the ONE definition of
+    `roofline.traffic` since round 6: reads = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x the rest, writes =
+    64 x WRREQ_64B + 32 x the rest (atomics included: they are write requests on this port).  Returns (read, write) or None when
+    the EA passes are missing.  FETCH_SIZE / WRITE_SIZE (the guide's generic recipe) stay in the file for comparison: on this
+    kernel FETCH_SIZE undercounts (it tallies the 16-byte-per-lane stream loads at half), which is why rounds 1-5 added half the
+    stream back by hand and ended up with two figures for one launch."""
+    rd = c.get("TCC_EA0_RDREQ_sum")
+    if not rd:
+        return None
+    n64, n128 = c.get("TCC_EA0_RDREQ_64B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+    read = 128.0 * n128 + 64.0 * n64 + 32.0 * max(0.0, rd - n64 - n128)
+    wr, w64 = c.get("TCC_EA0_WRREQ_sum", 0.0), c.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+    return read, 64.0 * w64 + 32.0 * max(0.0, wr - w64)
+
+
+ALGORITHMIC_BYTES_PER_BASE = 158.0 / 150.0                       # SURVEY.md 8d: 1 byte per base + 8 bytes of offset per 150 bp read
 
 
 def main():
@@ -46,14 +65,19 @@ def main():
     fetch_raw, write = per["FETCH_SIZE"] * 1024.0, per["WRITE_SIZE"] * 1024.0
     fetch = fetch_raw + 0.5 * stream
     cycles = per["GRBM_GUI_ACTIVE"] / 8.0                        # summed over the 8 XCDs
+    ms = memory_side_bytes(per)
     doc = {
         "source": "%s: separate rocprofv3 --pmc passes of tools/profile.sh (one counter group per pass, no trace domains)" % os.path.relpath(prof, ROOT),
         "kernel_source_sha16": kernel_source_sha16(),
         "bases_per_launch": bases,
         "fetch_bytes_per_launch_raw": fetch_raw, "write_bytes_per_launch": write, "fetch_bytes_per_launch_corrected": fetch,
         "correction": "+0.5 x stream bytes: FETCH_SIZE tallies 16-B/lane coalesced reads at half on gfx950; random 4/8/16-byte filter and table reads left as counted",
-        "traffic_bytes_per_base": (fetch + write) / bases,
-        "note": "fabric-side traffic (L2 misses): includes Infinity-Cache hits of the filters / key table; the read stream itself crosses HBM once",
+        "fetch_size_plus_half_stream_bytes_per_base": (fetch + write) / bases,     # rounds 1-5's figure, kept for comparison only
+        "traffic_bytes_per_base": (sum(ms) / bases) if ms else None,
+        "traffic_read_bytes_per_base": (ms[0] / bases) if ms else None, "traffic_write_bytes_per_base": (ms[1] / bases) if ms else None,
+        "traffic_over_algorithmic": (sum(ms) / bases / ALGORITHMIC_BYTES_PER_BASE) if ms else None,
+        "traffic_definition": "memory side of the L2: 128 x TCC_EA0_RDREQ_128B + 64 x TCC_EA0_RDREQ_64B + 32 x other reads + 64 x TCC_EA0_WRREQ_64B + 32 x other writes, per launch / bases",
+        "note": "memory-side traffic (L2 misses): includes Infinity-Cache hits of the filters / key table; the read stream itself crosses HBM once",
         "valu_insts_per_position": per["SQ_INSTS_VALU"] / (stream / 64.0) if per.get("SQ_INSTS_VALU") else None,
         "valu_busy_frac": per["SQ_INSTS_VALU"] * 4.2 / (1024.0 * cycles) if per.get("SQ_INSTS_VALU") and cycles else None,
         "valu_busy_note": "SQ_INSTS_VALU x 4.2 cycles per wave64 instruction (profiles/r02_microbench/valu_rate.txt) / (1024 SIMDs x GRBM_GUI_ACTIVE/8)",
