@@ -37,7 +37,7 @@ HIPLIB_TAB  := $(CSRC)/ntsm_tab_kernel.inc $(CSRC)/ntsm_tab_launch.inc $(CSRC)/n
 # $(call hiplib,output,extra flags,object dir): every source to its own object (in parallel; stale objects removed first and every
 # compile's exit status collected, so a failed translation unit fails the recipe instead of linking an old object), then one link
 define hiplib
-	@mkdir -p $(3)
+	@mkdir -p $(3) $(dir $(1))
 	rm -f $(3)/*.o
 	pids=""; for f in $(HIPLIB_DEV) $(HIPLIB_HOST); do $(HIPCC) $(HIPFLAGS) -fvisibility=hidden $(2) -c $$f -o $(3)/$$(basename $$f).o & pids="$$pids $$!"; done; \
 	rc=0; for p in $$pids; do wait $$p || rc=1; done; exit $$rc
@@ -47,21 +47,24 @@ endef
 ntsm_amd/libntsm_hip.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR)
 	$(call hiplib,$@,,build/obj)
 
+# Experiment and negative-result builds of the same ABI live under build/lib/, NOT in the package directory: the package ships
+# libntsm_hip.so, libntsm_host.so, libntsm_synth.so and libntsm_eval_hip.so only.  NTSM_HIP_LIB=<bare name> finds them there
+# (ntsm_amd/capi.py).
 # the same ABI with the tabulated k = 19 kernel compiled in (ntsm_set_kernel(ctx, 3)): a measured negative result kept
 # buildable and tested (tests/test_gpu_parity.py::test_tabulated_kernel_paths loads it through NTSM_HIP_LIB), not shipped
-tab: ntsm_amd/libntsm_hip_tab.so
-ntsm_amd/libntsm_hip_tab.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR) $(HIPLIB_TAB)
+tab: build/lib/libntsm_hip_tab.so
+build/lib/libntsm_hip_tab.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR) $(HIPLIB_TAB)
 	$(call hiplib,$@,-DNTSM_WITH_TAB,build/obj_tab)
 
 # design-study build: the two-level form with 12-mer minimizers instead of 14-mers, i.e. a
 # minimizer Bloom in front of the one-level kernel's own blocks -- tools/mid_study.sh measures it on the 2.5 M-key set
-m12: ntsm_amd/libntsm_hip_m12.so
-ntsm_amd/libntsm_hip_m12.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR)
+m12: build/lib/libntsm_hip_m12.so
+build/lib/libntsm_hip_m12.so: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR)
 	$(call hiplib,$@,-DNTSM_TWO_M=12,build/obj_m12)
 
-# experiment builds of the same ABI: make xlib XNAME=run96 XFLAGS="-DNTSM_RUN_C=96 ..." -> ntsm_amd/libntsm_hip_run96.so (NTSM_HIP_LIB selects it)
+# experiment builds of the same ABI: make xlib XNAME=run96 XFLAGS="-DNTSM_RUN_C=96 ..." -> build/lib/libntsm_hip_run96.so (NTSM_HIP_LIB selects it)
 xlib:
-	$(call hiplib,ntsm_amd/libntsm_hip_$(XNAME).so,$(XFLAGS),build/obj_$(XNAME))
+	$(call hiplib,build/lib/libntsm_hip_$(XNAME).so,$(XFLAGS),build/obj_$(XNAME))
 
 # ntsmEval all-pairs scoring: own library, own CLI
 ntsm_amd/libntsm_eval_hip.so: $(CSRC)/ntsm_eval.hip include/ntsm_eval_hip.h
@@ -73,13 +76,13 @@ build/ntsmEval: $(HOST)/ntsm_eval_main.cpp include/ntsm_eval_hip.h ntsm_amd/libn
 	    -Wl,-rpath,'$$ORIGIN/../ntsm_amd' -Wl,-rpath,/opt/rocm/lib
 
 # ablation builds (never shipped: wrong counts by construction).  `make ablation`: the default kernels with the switches of
-# ntsm_ablation.inc (NTSM_DEBUG_KERNEL ...) -> ntsm_amd/libntsm_hip_abl.so; `make ablation ABL="1 2 4"`: the tabulated
-# kernel's compile-time ablations as well -> ntsm_amd/libntsm_hip_abl<N>.so (tools/ablate.sh drives both)
+# ntsm_ablation.inc (NTSM_DEBUG_KERNEL ...) -> build/lib/libntsm_hip_abl.so; `make ablation ABL="1 2 4"`: the tabulated
+# kernel's compile-time ablations as well -> build/lib/libntsm_hip_abl<N>.so (tools/ablate.sh drives both)
 ablation: $(HIPLIB_DEV) $(HIPLIB_HOST) $(HIPLIB_HDR) $(HIPLIB_TAB) $(CSRC)/ntsm_ablation.inc
-	$(call hiplib,ntsm_amd/libntsm_hip_abl.so,-DNTSM_ABLATION $(ABLFLAGS),build/obj_abl)
+	$(call hiplib,build/lib/libntsm_hip_abl.so,-DNTSM_ABLATION $(ABLFLAGS),build/obj_abl)
 	for a in $(ABL); do $(MAKE) --no-print-directory abl_tab A=$$a; done
 abl_tab:
-	$(call hiplib,ntsm_amd/libntsm_hip_abl$(A).so,-DNTSM_WITH_TAB -DNTSM_ABLATION -DNTSM_TAB_ABL=$(A),build/obj_abl$(A))
+	$(call hiplib,build/lib/libntsm_hip_abl$(A).so,-DNTSM_WITH_TAB -DNTSM_ABLATION -DNTSM_TAB_ABL=$(A),build/obj_abl$(A))
 
 ntsm_amd/libntsm_synth.so: $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp -lz

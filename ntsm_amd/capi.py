@@ -17,10 +17,13 @@ class NtsmError(RuntimeError):
 
 
 def _load(name):
-    path = os.path.join(_HERE, name)
-    if not os.path.exists(path):
-        raise ImportError("%s is missing: run `make` at the repo root (the HIP path has no CPU fallback)" % path)
-    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    """The package's libraries lie beside this file.  An experiment build named through NTSM_HIP_LIB (`make tab / m12 / xlib /
+    ablation`: never shipped) is looked for under build/lib/ first; a name with a slash is taken as a path."""
+    cands = [name] if os.sep in name else [os.path.join(_HERE, name), os.path.join(os.path.dirname(_HERE), "build", "lib", name)]
+    for path in cands:
+        if os.path.exists(path):
+            return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    raise ImportError("%s is missing: run `make` at the repo root (the HIP path has no CPU fallback)" % cands[0])
 
 
 hip_lib = _load(os.environ.get("NTSM_HIP_LIB", "libntsm_hip.so"))   # env override: A/B builds of the same ABI

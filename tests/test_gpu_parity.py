@@ -1480,7 +1480,7 @@ def test_run_form_is_not_chosen_for_unrelated_kmers(nt):
 
 def test_tabulated_kernel_paths(nt, n10, tmp_path):
     """The tabulated k = 19 kernel is a measured negative result that lives behind -DNTSM_WITH_TAB: the default library
-    refuses ntsm_set_kernel(ctx, 3); `make tab` builds ntsm_amd/libntsm_hip_tab.so with it, and tests/tab_kernel_check.py
+    refuses ntsm_set_kernel(ctx, 3); `make tab` builds build/lib/libntsm_hip_tab.so with it, and tests/tab_kernel_check.py
     (a subprocess, because the library is chosen when ntsm_amd is imported) runs it against the oracle on the inputs that
     take its special paths."""
     s, sites, path = n10
