@@ -1856,6 +1856,8 @@ def test_bench_contract_line(nt):
     assert len(fr) == 2 and fr[0] <= fr[1] and set(fr) == {o["n10_full"]["roofline_frac"], r["frac"]}
     assert o["stress"]["reads"] == o["stress"]["reads_asked"] == 1000000
     assert o["n10_full"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["n10_full"]["site_kmers"] == 2 * 13 * 20000
+    am = o["n10_full"]["armed"]                                # -m on the same resident stream: exact stop, timed
+    assert am["early_stop"] is True and 0.3 < am["frac_of_stream"] < 0.5 and am["stop_read_is_first_crossing_by_generic_kernel_recount"] is True and am["wall_s"] > 0
     assert o["long"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["long"]["gbases_per_s"] > 0 and 0 < o["long"]["roofline_frac"] < 1
     assert o["long"]["m10"]["early_stop"] in (True, False) and o["long"]["m10"]["stop_read"] <= o["long"]["reads"]
     assert o["stress"]["check"]["equals_generic_kernel_on_the_whole_stream"] and o["stress"]["gbases_per_s"] > 0

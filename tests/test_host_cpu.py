@@ -123,6 +123,25 @@ def test_c_abi_exports_every_declared_symbol(nt):
     assert total >= 40
 
 
+def test_round6_entry_points_check_their_arguments(nt):
+    """The entry points added in round 6 refuse bad arguments before they touch the HIP runtime (no GPU needed): NULL contexts and
+    buffers, thread counts out of range, unknown key kinds."""
+    import ctypes as C
+    H = nt.hip_lib
+    u8p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
+    ends = (C.c_uint64 * 1)(150)
+    buf = (C.c_uint8 * 151)()
+    assert H.ntsm_submit_pinned(None, C.cast(buf, u8p), 151, C.cast(ends, u64p), 1) == -1          # NTSM_ERR_ARG
+    assert H.ntsm_set_submit_threads(None, 2) == -1
+    assert H.ntsm_host_pin(None, 4096) == -1 and H.ntsm_host_pin(C.cast(buf, C.c_void_p), 0) == -1 and H.ntsm_host_unpin(None) == -1
+    f = C.c_int(-1)
+    keys = (C.c_uint64 * 2)(5, 9)
+    assert H.ntsm_debug_form_choice(C.cast(keys, u64p), 2, 19, 7, C.byref(f)) == -1               # unknown key kind
+    assert H.ntsm_debug_form_choice(C.cast(keys, u64p), 2, 0, 0, C.byref(f)) == -1                # k out of range
+    assert H.ntsm_debug_form_choice(C.cast(keys, u64p), 2, 19, 0, None) == -1
+    assert H.ntsm_debug_form_choice(C.cast(keys, u64p), 2, 19, 0, C.byref(f)) == 0 and f.value == 0   # two keys: the one-level form
+
+
 def test_no_cpu_fallback(nt):
     """Without a GPU the product must fail loudly, never silently count on the CPU."""
     import torch

@@ -42,7 +42,7 @@ for spec in (sys.argv[1:] or ["0:0"]):
     cur = (t.total_kmers // 3, t.total_hits // 3)
     assert ref is None or cur == ref, (spec, cur, ref)
     ref = cur
-    print(json.dumps({"lib": os.environ.get("NTSM_HIP_LIB", "libntsm_hip.so"), "spec": spec, "two_level": st["two_level"], "bloom_MiB": st["bloom_words"] * 4 / 2 ** 20,
+    print(json.dumps({"lib": os.environ.get("NTSM_HIP_LIB", "libntsm_hip.so"), "spec": spec, "two_level": st["two_level"], "run_form": st.get("run_form", False), "bloom_MiB": st["bloom_words"] * 4 / 2 ** 20,
                       "site_minimizers": st["site_minimizers"], "site_kmers": len(sites.keys), "reads": n_reads, "kernel_ms": ms / n,
                       "gbases_per_s": n_reads * 150 / (ms / n / 1e3) / 1e9, "hits_per_pass": cur[1]}), flush=True)
     ctx.close()

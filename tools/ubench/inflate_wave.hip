@@ -198,7 +198,10 @@ __device__ __forceinline__ uint32_t slow_symbol(BitReader &br, const uint32_t *c
 
 __constant__ uint8_t kPreOrder[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 
-__global__ __launch_bounds__(64) void inflate_tokens(const uint32_t *__restrict__ comp, const ChunkDesc *__restrict__ chunks, uint32_t *__restrict__ tokens,
+#ifndef INFLATE_WAVES_PER_SIMD
+#define INFLATE_WAVES_PER_SIMD 4               /* register budget: 4 = what the compiler takes by itself (100 VGPRs); -DINFLATE_WAVES_PER_SIMD=8 caps it at 64 */
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INFLATE_WAVES_PER_SIMD, INFLATE_WAVES_PER_SIMD))) void inflate_tokens(const uint32_t *__restrict__ comp, const ChunkDesc *__restrict__ chunks, uint32_t *__restrict__ tokens,
 		unsigned long long *__restrict__ n_tokens, unsigned long long *__restrict__ n_out, uint32_t *__restrict__ status)
 {
 	__shared__ WaveLds L;
