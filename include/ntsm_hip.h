@@ -204,7 +204,7 @@ int ntsm_set_armed_chunk(ntsm_ctx *ctx, uint64_t chunk_bytes);
  *   0  automatic: 13 <= k <= 31 the minimizer-blocked kernel, other k the generic kernel; 15 <= k <= 31 with a site set
  *      whose blocked filter is well out of the L2 (more than ~3.1 M k-mers) takes the two-level form of the kernel: 14-mer
  *      minimizers and a Bloom word over the distinct site minimizers in front of the block;
- *      k = 19 with 1.8 M <= site k-mers < 9 M takes the run-anchored kernel (5) for unarmed batches
+ *      k = 19 with 1.8 M <= site k-mers < 8 M takes the run-anchored kernel (5) for unarmed batches
  *   1  always the generic kernel
  *   2  the minimizer-blocked kernel, one level, whatever the size of the set
  *   4  15 <= k <= 31 only: the two-level form, whatever the size of the set

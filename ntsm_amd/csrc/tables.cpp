@@ -42,9 +42,13 @@ bool wants_two_level(uint64_t n_keys) { return (12ull * n_keys + 127) / 128 > (9
  * the run kernel's queues were made to outlive their tile): 1.04 M keys 847 / 848, 1.3 M 847 / 857, 1.56 M 805 / 843, 2.0 M 715 / 831,
  * 2.5 M 656 / 832, 3.4 M 616 / 808, 4.2 M 605 / 777, 5.7 M 563 / 649, 8.3 M 521 / 562, 10.4 M 502 / 486, 13.5 M 470 / 372; the bench
  * set (1.54 M keys, 3 .. 13 k-mers kept per window) 862 / 866.  Below 1.8 M keys the two are level (the one-level minimizer-blocked
- * filter still fits the L2) and the minimizer-blocked kernel stays; from 9 M keys on the two-level form's minimizer Bloom is
+ * filter still fits the L2) and the minimizer-blocked kernel stays; from 8-9 M keys on the two-level form's minimizer Bloom is
  * the better L2 resident. */
-bool wants_run_form(int k, uint64_t n_keys) { return k == NTSM_FAST_K && n_keys >= 1800000ull && n_keys < 9000000ull; }
+/* A second synthetic family (round 6, tools/window_family.sh: 3 .. 13 k-mers kept per allele, the bench set's structure; one level / two
+ * levels / run form): 1.54 M keys 890 / 679 / 857, 1.84 M 809 / 665 / 849, 2.16 M 751 / 657 / 847, 2.56 M 717 / 651 / 830, 3.36 M 492 / 637 / 793,
+ * 4.33 M 394 / 608 / 684, 6.09 M 322 / 567 / 609, 8.97 M 279 / 525 / 451, 12.0 M 252 / 476 / 308: the lower edge holds, the upper edge lies between
+ * 6.1 and 9.0 M keys there (8.3 - 10.4 M on the first family) -- 8 M is the compromise (at most 8 % lost on either family next to the edge). */
+bool wants_run_form(int k, uint64_t n_keys) { return k == NTSM_FAST_K && n_keys >= 1800000ull && n_keys < 8000000ull; }
 
 uint64_t mask_for_k(int k) { return k >= 32 ? 0ull : ((1ull << (2 * k)) - 1); }   /* k = 32: see include/ntsm_hip.h */
 

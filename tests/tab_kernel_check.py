@@ -77,7 +77,7 @@ for flog in (0, 20, 25, 124):
 import tempfile
 with tempfile.TemporaryDirectory() as d:
     bp = os.path.join(d, "big.fa")
-    sb = nt.SynthShort(sites_seed=777, n_sites=600_000, read_seed=3, p_embed=0.3, sites_path=bp)   # from 9 M keys on two levels are the automatic choice (below: the run-anchored kernel)
+    sb = nt.SynthShort(sites_seed=777, n_sites=600_000, read_seed=3, p_embed=0.3, sites_path=bp)   # from 8 M keys on two levels are the automatic choice (below: the run-anchored kernel)
     big = nt.Sites(bp)
     assert len(big.keys) > 7_000_000
     n = 4000

@@ -548,7 +548,7 @@ def test_random_reads_vs_oracle_n10_full(nt, tmp_path):
     fp.L.ntsm_oracle_fp_insert_count(fp.h, bases.tobytes(), bases.size)
     want = fp.kmers()[2]
     assert fp.total_hits > 150_000
-    # a set of this size takes the run-anchored kernel by itself (1.8 M <= keys < 9 M: measured 832 against 656 Gbases/s); 2 forces
+    # a set of this size takes the run-anchored kernel by itself (1.8 M <= keys < 8 M: measured 832 against 656 Gbases/s); 2 forces
     # the one-level minimizer-blocked form, an explicit filter size (2000000 + KiB without ntsm_set_kernel 5) keeps it as well
     for variant, tun in ((0, 0), (1, 0), (4, 0), (2, 0), (0, 2002048), (2, 3000021), (5, 0), (5, 2001536)):
         ctx = nt.Context(sites.keys)
@@ -1435,7 +1435,7 @@ def test_run_form_is_chosen_whatever_the_order_of_the_keys(nt, tmp_path):
 
 
 def test_run_form_is_not_chosen_for_unrelated_kmers(nt):
-    """The automatic choice of the run-anchored kernel needs more than a key count in its window (1.8 M <= keys < 9 M): the site
+    """The automatic choice of the run-anchored kernel needs more than a key count in its window (1.8 M <= keys < 8 M): the site
     set must have the cluster structure the kernel feeds on -- consecutive keys that share minimizer and anchored 16-mer, as the
     k-mers of ntsm's 31-base windows do (tables.cpp: run_form_pays).  2 M UNRELATED random 19-mers: the automatic choice stays on
     the minimizer-blocked kernel; forced (5) the run form still counts exactly (its filter just holds one signature per key)."""
