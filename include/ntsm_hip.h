@@ -139,7 +139,8 @@ int ntsm_lane_acquire_packed(ntsm_lane *lane, uint8_t **codes, uint8_t **valid, 
 int ntsm_lane_submit_packed(ntsm_lane *lane, uint64_t n_positions, uint32_t n_reads, uint64_t n_bases);
 
 /* Initialise the HIP runtime and the device context of `device` and put `n_streams` ready-made streams into the
- * library's per-device stream pool (a context takes 3, plus 2 once it has lanes; streams go back to the pool when
+ * library's per-device stream pool (a context takes 4 -- two staging slots, resident batches, and the ONE copy stream every
+ * host-to-device batch copy of the context is issued on --, plus 2 once it has lanes; streams go back to the pool when
  * the context is destroyed).  Thread-safe.  Creating a stream costs ~14 ms on this runtime, so a host calls this on a side thread
  * while it loads the sites file (src/FingerPrint.hpp:489-572), before ntsm_create.  Optional: everything is
  * created on demand otherwise. */

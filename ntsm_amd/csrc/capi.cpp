@@ -136,6 +136,7 @@ int ntsm_create(ntsm_ctx **out, int device, int k, const uint64_t *keys, uint32_
 	if (hipDeviceSynchronize() != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (dev_malloc(&c->d_vec, ((uint64_t) n_kmers + 4) * sizeof(uint64_t)) != hipSuccess) return fail(NTSM_ERR_HIP);
 	if (!(c->rstream = stream_get(device))) return fail(NTSM_ERR_HIP);
+	if (!(c->cstream = stream_get(device))) return fail(NTSM_ERR_HIP);
 	for (int i = 0; i < kTimingPool; ++i) {
 		if (hipEventCreate(&c->ev_a[i]) != hipSuccess || hipEventCreate(&c->ev_b[i]) != hipSuccess) return fail(NTSM_ERR_HIP);
 	}
@@ -152,8 +153,10 @@ void ntsm_destroy(ntsm_ctx *c)
 		free_slot(s);
 		stream_put(c->device, s.stream);
 		if (s.done) (void) hipEventDestroy(s.done);
+		if (s.copied) (void) hipEventDestroy(s.copied);
 	}
 	stream_put(c->device, c->rstream);
+	stream_put(c->device, c->cstream);
 	for (hipStream_t st : c->lane_stream) stream_put(c->device, st);
 	for (int i = 0; i < kTimingPool; ++i) {
 		if (c->ev_a[i]) (void) hipEventDestroy(c->ev_a[i]);
@@ -350,7 +353,12 @@ int ntsm_lane_submit(ntsm_lane *l, uint64_t n_bytes, uint32_t n_reads)
 	if (n_reads == 0) return NTSM_OK;
 	ntsm_ctx *c = l->c;
 	LANECHK(hipSetDevice(c->device));
-	LANECHK(h2d_async(s.d_bases, s.h_bases, n_bytes, s.stream));
+	{
+		void *const dst[1] = { s.d_bases };
+		const void *const src[1] = { s.h_bases };
+		const size_t bytes[1] = { (size_t) n_bytes };
+		LANECHK(slot_copy(c, s, dst, src, bytes, 1));
+	}
 	rc = launch_count(c, s.stream, s.d_bases, 0, n_bytes, nullptr, 0, false, +1);
 	if (rc) return lane_lost_batch(l, rc);
 	LANECHK(hipEventRecord(s.done, s.stream));
@@ -398,8 +406,12 @@ int ntsm_lane_submit_packed(ntsm_lane *l, uint64_t n_positions, uint32_t n_reads
 	const uint64_t n_out = (n_positions + 31) & ~31ull;
 	uint8_t *h_valid = s.h_bases + cap_pos / 4;
 	for (uint64_t p = n_positions; p < n_out; p += 8) h_valid[p >> 3] = 0;
-	LANECHK(h2d_async(s.d_packed, s.h_bases, n_out / 4, s.stream));
-	LANECHK(h2d_async(s.d_packed + cap_pos / 4, h_valid, n_out / 8, s.stream));
+	{
+		void *const dst[2] = { s.d_packed, s.d_packed + cap_pos / 4 };
+		const void *const src[2] = { s.h_bases, h_valid };
+		const size_t bytes[2] = { (size_t) (n_out / 4), (size_t) (n_out / 8) };
+		LANECHK(slot_copy(c, s, dst, src, bytes, 2));
+	}
 	const uint64_t n16 = n_out / 16;
 	LANECHK(launch_unpack((const uint32_t *) s.d_packed, (const uint16_t *) (s.d_packed + cap_pos / 4), s.d_bases, (unsigned long long) n16, s.stream));
 	int rc = launch_count(c, s.stream, s.d_bases, 0, n_out, nullptr, 0, false, +1);
@@ -423,6 +435,7 @@ int ntsm_lane_close(ntsm_lane *l)
 		s.busy = false;
 		free_slot(s, c);                                  /* device buffers go to the context's cache (nothing of this lane is in flight any more) */
 		if (s.done) (void) hipEventDestroy(s.done);
+		if (s.copied) (void) hipEventDestroy(s.copied);
 	}
 	{
 		std::lock_guard<std::mutex> lk(c->mu);
@@ -516,11 +529,17 @@ int ntsm_submit_pinned(ntsm_ctx *c, const uint8_t *bases, uint64_t n_bytes, cons
 	if (rc) return rc;
 	c->reduced = false;
 	c->next_slot ^= 1;
-	HIPCHK(h2d_async(s.d_bases, bases, n_bytes, s.stream));
 	if (c->armed) {
+		HIPCHK(h2d_async(s.d_bases, bases, n_bytes, s.stream));
 		memcpy(s.h_read_end, read_end, (size_t) n_reads * sizeof(uint64_t));
 		HIPCHK(h2d_async(s.d_read_end, s.h_read_end, n_reads * sizeof(uint64_t), s.stream));
 		return armed_batch(c, s.stream, s.d_bases, n_bytes, s.d_read_end, s.h_read_end, n_reads);   /* synchronous: the buffer is free on return */
+	}
+	{
+		void *const dst[1] = { s.d_bases };
+		const void *const src[1] = { bases };
+		const size_t nb[1] = { (size_t) n_bytes };
+		HIPCHK(slot_copy(c, s, dst, src, nb, 1));
 	}
 	rc = launch_count(c, s.stream, s.d_bases, 0, n_bytes, nullptr, 0, false, +1);
 	if (rc) return rc;
@@ -565,6 +584,7 @@ int ntsm_sync(ntsm_ctx *c, ntsm_totals *t)
 		s.busy = false;
 	}
 	HIPCHK(hipStreamSynchronize(c->rstream));
+	HIPCHK(hipStreamSynchronize(c->cstream));                /* (every copy there is followed by a kernel that was just waited for) */
 	if (t) {
 		memset(t, 0, sizeof *t);
 		if (c->reduced) {

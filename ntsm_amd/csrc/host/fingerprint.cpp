@@ -306,7 +306,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 			const int d = m_ctxDevice[i];
 			const bool first = i == 0;
 			m_prep.emplace_back([d, first, pool_bytes, lanes_per_dev]() {
-				if (ntsm_warmup(d, lanes_per_dev ? 5 : 3) != NTSM_OK) return;   /* a context's 3 streams + its 2 lane streams; ntsm_create reports failures */
+				if (ntsm_warmup(d, lanes_per_dev ? 6 : 4) != NTSM_OK) return;   /* a context's 4 streams (two slots, resident, copy) + its 2 lane streams; ntsm_create reports failures */
 				if (first) (void) ntsm_staging_pool(pool_bytes);
 			});
 		}

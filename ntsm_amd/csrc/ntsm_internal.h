@@ -74,6 +74,7 @@ struct Slot {
 	bool ends_on_device = true;                /* false (lanes): read_end never leaves the host, plain malloc */
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;                 /* last use of the host buffer finished */
+	hipEvent_t copied = nullptr;               /* the batch's H2D copies (on the context's copy stream) finished: what the slot's kernels wait for */
 	bool busy = false, acquired = false;
 };
 
@@ -164,6 +165,11 @@ struct ntsm_ctx {
 	int next_slot = 0;
 	uint64_t cap_bytes = 64ull << 20, cap_reads = 1ull << 20;
 	hipStream_t rstream = nullptr;             /* stream for resident batches */
+	/* ALL host-to-device batch copies of a context (staging slots, ntsm_submit_pinned, every lane) are issued on this ONE stream, in
+	 * submission order; a slot's kernels run on the slot's own stream behind the slot's `copied` event.  Copies on two streams share
+	 * the link instead of following each other; on most boxes that costs nothing, on some it does (pinned hipMemcpyAsync of 64 MiB
+	 * batches alternating on two streams 48 GB/s against 56.8 on one, and ntsm_submit 36 instead of 51: DESIGN.md section 5.1). */
+	hipStream_t cstream = nullptr;
 	ntsm_rt::CopyPool *copy_pool = nullptr;    /* ntsm_submit's staging copy on several threads (created on the first large batch) */
 	int submit_threads = 0;                    /* threads of that copy, the submitting one included (0 = automatic: min(6, CPUs of the affinity mask)) */
 	/* host-side totals */
@@ -250,6 +256,8 @@ int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool
 int slot_add_host_bases(Slot &s);            /* pin the bases staging of a slot created without one (ntsm_submit_pinned came first) */
 void staged_copy(ntsm_ctx *c, uint8_t *dst, const uint8_t *src, uint64_t n);   /* ntsm_submit: the batch into the pinned slot, on submit_threads threads */
 void copy_pool_release(ntsm_ctx *c);
+/* enqueue `n_copies` host-to-device copies of one batch on the context's copy stream and make the slot's stream wait for them */
+hipError_t slot_copy(ntsm_ctx *c, Slot &s, void *const *dst, const void *const *src, const size_t *bytes, int n_copies);
 void free_slot(Slot &s, ntsm_ctx *cache = nullptr);
 int launch_count(ntsm_ctx *c, hipStream_t st, const uint8_t *d_bases, uint64_t lo, uint64_t hi,
 		const uint64_t *d_read_end, uint64_t n_reads, bool per_read, int sign);

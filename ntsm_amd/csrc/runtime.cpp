@@ -312,6 +312,7 @@ int alloc_slot(Slot &s, int device, uint64_t cap_bytes, uint64_t cap_reads, bool
 	/* (events with hipEventBlockingSync -- waiting threads sleep instead of spinning -- were measured on the 16-CPU pod: no gain for
 	 * 16 packed lanes, 68.5 vs 67.3 Gbases/s, and ntsm_submit 25 % slower, 39.9 vs 53.4 GB/s: NOTEBOOK.md round 6) */
 	if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+	if (!s.copied) HIPCHK(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
 	s.busy = false;
 	s.acquired = false;
 	return NTSM_OK;
@@ -612,13 +613,30 @@ int check_layout(const uint64_t *read_end, uint32_t n_reads, uint64_t n_bytes)
 	return NTSM_OK;
 }
 
+hipError_t slot_copy(ntsm_ctx *c, Slot &s, void *const *dst, const void *const *src, const size_t *bytes, int n_copies)
+{
+	for (int i = 0; i < n_copies; ++i) {
+		const hipError_t e = h2d_async(dst[i], src[i], bytes[i], c->cstream);
+		if (e != hipSuccess) return e;
+	}
+	hipError_t e = hipEventRecord(s.copied, c->cstream);     /* lanes enqueue concurrently: the event may also cover a neighbour's copy, never less than ours */
+	if (e != hipSuccess) return e;
+	return hipStreamWaitEvent(s.stream, s.copied, 0);
+}
+
 int submit_slot(ntsm_ctx *c, Slot &s, uint64_t n_bytes, uint32_t n_reads)
 {
 	if (n_reads == 0) return NTSM_OK;
-	HIPCHK(h2d_async(s.d_bases, s.h_bases, n_bytes, s.stream));
-	if (c->armed) {
+	if (c->armed) {                                          /* synchronous anyway: everything on the slot's stream */
+		HIPCHK(h2d_async(s.d_bases, s.h_bases, n_bytes, s.stream));
 		HIPCHK(h2d_async(s.d_read_end, s.h_read_end, n_reads * sizeof(uint64_t), s.stream));
 		return armed_batch(c, s.stream, s.d_bases, n_bytes, s.d_read_end, s.h_read_end, n_reads);
+	}
+	{
+		void *const dst[1] = { s.d_bases };
+		const void *const src[1] = { s.h_bases };
+		const size_t bytes[1] = { (size_t) n_bytes };
+		HIPCHK(slot_copy(c, s, dst, src, bytes, 1));
 	}
 	int rc = launch_count(c, s.stream, s.d_bases, 0, n_bytes, nullptr, 0, false, +1);
 	if (rc) return rc;
