@@ -18,7 +18,7 @@ HOSTSRC  := $(HOST)/seq_reader.cpp $(HOST)/site_set.cpp $(HOST)/report.cpp $(HOS
             $(HOST)/inflate.cpp $(HOST)/inflate_spec.cpp $(HOST)/gz_stream.cpp $(HOST)/gz_parallel.cpp $(HOST)/crc32_fast.cpp $(HOST)/pack2.cpp
 HOSTHDR  := $(wildcard $(HOST)/*.hpp) include/ntsm_host.h include/ntsm_hip.h
 
-all: oracle_all build/ntsm_synth build/gather_bench build/ntsm_feed_bench build/ubench/inflate_wave ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount ntsm_amd/libntsm_eval_hip.so build/ntsmEval
+all: oracle_all build/ntsm_synth build/gather_bench build/ntsm_feed_bench build/ubench/inflate_wave ntsm_amd/libntsm_hip.so ntsm_amd/libntsm_synth.so ntsm_amd/libntsm_host.so build/ntsmCount ntsm_amd/libntsm_eval_hip.so build/ntsmEval ref_gpu_binding
 
 # host-only pieces (reader, site loader, report formatting): no HIP dependency
 ntsm_amd/libntsm_host.so: $(HOSTSRC) $(HOST)/early_ingest.cpp $(HOST)/host_capi.cpp $(HOSTHDR)
@@ -89,6 +89,10 @@ ntsm_amd/libntsm_synth.so: $(CSRC)/synth_dev.hip $(CSRC)/synth_host.cpp $(CSRC)/
 
 oracle_all:
 	$(MAKE) -C oracle all
+# INTEGRATION.md section 2 compiled around the unmodified reference class and linked against the product library (test
+# infrastructure: oracle/ref_gpu_binding.cpp -> oracle/_ref/ref_gpu_ntsmCount; only where /root/reference exists)
+ref_gpu_binding: ntsm_amd/libntsm_hip.so
+	$(MAKE) -C oracle refgpu
 
 build/ntsm_synth: tools/ntsm_synth.cpp $(CSRC)/synth_host.cpp $(CSRC)/synth.h include/ntsm_synth.h
 	@mkdir -p build
@@ -112,4 +116,4 @@ build/gather_bench: tools/gather_bench.hip
 clean:
 	rm -rf build ntsm_amd/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle_all clean ablation abl_tab tab m12 xlib
+.PHONY: all oracle_all ref_gpu_binding clean ablation abl_tab tab m12 xlib
