@@ -173,7 +173,9 @@ int ntsm_counts(ntsm_ctx *ctx, uint64_t *out);
  * vector back so that ntsm_counts/ntsm_sync report job-wide values. */
 int ntsm_counts_device(ntsm_ctx *ctx, void **d_vec, uint64_t *n_words);
 int ntsm_import_reduced(ntsm_ctx *ctx);
-/* Single-process multi-GPU merge: RCCL SUM over the n contexts' count vectors + totals (xGMI). */
+/* Single-process multi-GPU merge: RCCL SUM over the n contexts' count vectors + totals (xGMI); afterwards every context
+ * reports the job-wide result.  Contexts that share a device are summed there first and RCCL runs between one context per
+ * distinct device -- with a single distinct device no collective runs at all (`ntsmCount -g 0,0`). */
 int ntsm_allreduce(ntsm_ctx *const *ctxs, int n);
 /* Bind RCCL now (dlopen of librccl.so.1 + the five entry points ntsm_allreduce calls: ncclCommInitAll, ncclGroupStart,
  * ncclGroupEnd, ncclAllReduce, ncclCommDestroy) and say whether it worked: NTSM_OK or NTSM_ERR_RCCL.  Touches no GPU.

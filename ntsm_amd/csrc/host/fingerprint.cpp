@@ -1,6 +1,7 @@
 #include "fingerprint.hpp"
 
 #include <algorithm>
+#include <set>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -288,8 +289,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 	m_plan = ingest_plan(std::max(1u, m_opt.threads), granted_cpus());
 	if (m_opt.threads > 1) m_opt.threads = std::max(2u, std::min(m_opt.threads, std::max(m_plan.feeders, 2u)));   /* 2 at least: keeps the lane path (and its tests) on a 1-CPU grant */
 	if (m_opt.devices.empty()) m_opt.devices.push_back(m_opt.device);
-	for (int d : m_opt.devices)
-		if (std::find(m_ctxDevice.begin(), m_ctxDevice.end(), d) == m_ctxDevice.end()) m_ctxDevice.push_back(d);
+	m_ctxDevice = m_opt.devices;                          /* one context per LISTED device: `-g 0,0` = two contexts on device 0, merged on the device (ntsm_allreduce) */
 	/* Side threads, one per device, prepare everything that does not depend on the sites while this thread parses
 	 * them: runtime + device context, the three streams of a context, the pinned staging pool (first device),
 	 * the two streams its lanes share.  They are joined when the first batch is about to be staged (computeCounts). */
@@ -349,7 +349,7 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 		joinPrep();
 		exit(1);
 	}
-	/* one context per distinct device; with -m everything runs on the first one */
+	/* one context per listed device; with -m everything runs on the first one */
 	if (m_maxCounts != 0) m_ctxDevice.resize(1);
 	m_ctx.assign(m_ctxDevice.size(), nullptr);
 	std::vector<int> rcs(m_ctxDevice.size(), 0);
@@ -362,7 +362,8 @@ FingerPrint::FingerPrint(const Options &opt) : m_opt(opt)
 	for (auto &t : mk) t.join();
 	/* several devices end with one RCCL SUM (fetchResults): bind the library now, so that a host without it hears
 	 * about it before the work, not after (the host-side sum of fetchResults takes over in that case) */
-	if (m_ctx.size() > 1 && ntsm_rccl_probe() != NTSM_OK)
+	const size_t n_distinct_devices = std::set<int>(m_ctxDevice.begin(), m_ctxDevice.end()).size();   /* contexts on ONE device are merged without RCCL */
+	if (n_distinct_devices > 1 && ntsm_rccl_probe() != NTSM_OK)
 		std::cerr << "ntsmCount: warning: RCCL could not be loaded; the devices' counts will be summed on the host" << std::endl;
 	if (m_opt.phase_times)
 		std::cerr << "[phase] sites parsed " << std::chrono::duration<double>(tc1 - tc0).count() << " s, contexts (tables + upload) "
@@ -404,9 +405,7 @@ void FingerPrint::joinPrep()
 Feeder &FingerPrint::feederFor(size_t t)
 {
 	if (!m_lanes[t]) {
-		const int dev = m_opt.devices[t % m_opt.devices.size()];
-		const size_t ci = (size_t) (std::find(m_ctxDevice.begin(), m_ctxDevice.end(), dev) - m_ctxDevice.begin());
-		m_lanes[t].reset(new Feeder(m_opt, m_ctx[ci], 0, true));
+		m_lanes[t].reset(new Feeder(m_opt, m_ctx[t % m_ctx.size()], 0, true));   /* threads round-robin over the contexts */
 	}
 	return *m_lanes[t];
 }

@@ -3,8 +3,9 @@
  *   ntsmCount -s sites.fa [-t N] [-m COV] [-o summary] [-d] [-k K] [-v] reads.fq[.gz] ... > counts.txt
  * stdout: "#@TK", "#@KS" headers + one row per site (countAT/countCG = max per-k-mer count of the
  * allele).  stderr: collision warnings, the six summary lines, "Time: .. s Memory: .. kbytes".
- * New, optional: -g/--gpu INT[,INT...] selects the HIP device(s) (default 0); with -t N and several files the host
- * threads are spread round-robin over the listed devices and the per-k-mer counts are summed on the host.
+ * New, optional: -g/--gpu INT[,INT...] selects the HIP device(s) (default 0): one context per listed device, with -t N the host
+ * threads are spread round-robin over them and the per-k-mer counts are merged by one RCCL SUM (ntsm_allreduce).  A device listed
+ * twice gets two contexts, merged on the device without RCCL -- `-g 0,0` runs the whole multi-context path on a one-GPU host.
  */
 #include <getopt.h>
 #include <sched.h>

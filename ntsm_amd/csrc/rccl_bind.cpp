@@ -1,6 +1,7 @@
 /*
  * rccl_bind.cpp -- the one collective of the count path: SUM all-reduce of every context's dense count vector + totals
- * (uint64[n_kmers + 4]) across the GPUs of ONE process (ntsm_allreduce; `ntsmCount -g a,b`), RCCL over xGMI.
+ * (uint64[n_kmers + 4]) across the GPUs of ONE process (ntsm_allreduce; `ntsmCount -g a,b`), RCCL over xGMI; contexts that
+ * share a device are summed on that device first.
  * SUM, not MAX: the per-site maxima are taken on the host from the summed per-k-mer counts, which is what a single
  * reference run computes (src/FingerPrint.hpp:281-294); the reference itself has no multi-device path (only
  * `omp parallel for` over files on one shared table, src/FingerPrint.hpp:46-48).
@@ -51,15 +52,13 @@ const Rccl &rccl_bind()
 
 bool rccl_available() { return rccl_bind().ok; }
 
-int rccl_group_allreduce(ntsm_ctx *const *ctxs, int n)
+/* RCCL SUM between contexts on DISTINCT devices (one communicator rank per device). */
+static int rccl_between_devices(ntsm_ctx *const *ctxs, int n)
 {
 	const Rccl &rccl = rccl_bind();
 	if (!rccl.ok) return NTSM_ERR_RCCL;
 	std::vector<int> devs(n);
 	for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
-	for (int i = 0; i < n; ++i)
-		for (int j = 0; j < i; ++j)
-			if (devs[i] == devs[j]) return NTSM_ERR_ARG;    /* one context per device */
 	/* Communicators are kept per device list for the life of the process: ncclCommInitAll costs far more than the
 	 * 12 MB reduction it serves (tens of milliseconds against well under one). */
 	static std::mutex comm_mu;
@@ -85,6 +84,51 @@ int rccl_group_allreduce(ntsm_ctx *const *ctxs, int n)
 		if (hipStreamSynchronize(ctxs[i]->rstream) != hipSuccess) ok = false;
 	}
 	if (!ok) return NTSM_ERR_RCCL;
+	return NTSM_OK;
+}
+
+/* The merge of ntsm_allreduce.  Contexts that share a device need no collective: their vectors are summed into the first
+ * of them (through the host: 8 bytes per site k-mer, once per run), RCCL then runs between one context per distinct device, and
+ * the result is copied back to the others on the device.  With a single distinct device -- `ntsmCount -g 0,0`, two contexts
+ * on one GPU -- RCCL is not touched at all, so the whole multi-context path of the host side (threads spread over contexts,
+ * one merge, every context reporting the job-wide result) also runs on a one-GPU machine. */
+int rccl_group_allreduce(ntsm_ctx *const *ctxs, int n)
+{
+	const size_t words = (size_t) ctxs[0]->n_kmers + 4;
+	std::vector<int> leader(n);                            /* index of the first context on the same device */
+	std::vector<ntsm_ctx *> leaders;
+	for (int i = 0; i < n; ++i) {
+		leader[i] = i;
+		for (int j = 0; j < i; ++j)
+			if (ctxs[j]->device == ctxs[i]->device) { leader[i] = leader[j]; break; }
+		if (leader[i] == i) leaders.push_back(ctxs[i]);
+	}
+	if ((int) leaders.size() < n) {
+		std::vector<uint64_t> sum(words), part(words);
+		for (int l = 0; l < n; ++l) {
+			if (leader[l] != l) continue;
+			bool shared = false;
+			for (int i = l + 1; i < n; ++i) shared |= leader[i] == l;
+			if (!shared) continue;
+			HIPCHK(hipSetDevice(ctxs[l]->device));
+			HIPCHK(hipMemcpy(sum.data(), ctxs[l]->d_vec, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+			for (int i = l + 1; i < n; ++i) {
+				if (leader[i] != l) continue;
+				HIPCHK(hipMemcpy(part.data(), ctxs[i]->d_vec, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+				for (size_t w = 0; w < words; ++w) sum[w] += part[w];
+			}
+			HIPCHK(hipMemcpy(ctxs[l]->d_vec, sum.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
+		}
+	}
+	if (leaders.size() > 1) {
+		const int rc = rccl_between_devices(leaders.data(), (int) leaders.size());
+		if (rc) return rc;                                  /* nothing has been imported: every context still reports its own counts */
+	}
+	for (int i = 0; i < n; ++i) {
+		if (leader[i] == i) continue;
+		HIPCHK(hipSetDevice(ctxs[i]->device));
+		HIPCHK(hipMemcpy(ctxs[i]->d_vec, ctxs[leader[i]]->d_vec, words * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+	}
 	return NTSM_OK;
 }
 

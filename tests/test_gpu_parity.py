@@ -751,6 +751,54 @@ def test_two_devices_allreduce_cli_and_ordered_stop(nt, n10, tmp_path):
     [c.close() for c in ctxs]
 
 
+def test_allreduce_and_cli_with_several_contexts_on_one_device(nt, n10, tmp_path):
+    """The multi-context path on ONE GPU: contexts that share a device are summed on the device (no RCCL), so ntsm_allreduce,
+    the CLI's thread -> context round robin and its single merge run here as they do with `-g 0,1` -- only the collective
+    between distinct devices stays for a multi-GPU node (test_two_devices_allreduce_cli_and_ordered_stop).
+    (a) 2 and 3 contexts on device 0, each counting its share of the reads, ntsm_allreduce: every context reports the
+    oracle's job-wide counts and totals, twice in a row; (b) `ntsmCount -g 0,0 -t 2` / `-g 0,0,0 -t 4` print the bytes of
+    `-g 0`; with -m the run stays on the first context."""
+    s, sites, path = n10
+    n = 150_000
+    bases, ends = s.host_bytes(0, n), s.read_end(n)
+    fp = OracleFP(path)
+    fp.process_flat(bases, ends)
+    for world in (2, 3):
+        ctxs = [nt.Context(sites.keys, device=0) for _ in range(world)]
+        cut = [n * r // world for r in range(world + 1)]
+        for rep in (1, 2):
+            for r, c in enumerate(ctxs):
+                lo = cut[r] * s.stride
+                c.submit(bases[lo:cut[r + 1] * s.stride], ends[cut[r]:cut[r + 1]] - np.uint64(lo))
+            nt.allreduce(ctxs)
+            for c in ctxs:
+                t = c.sync()
+                assert np.array_equal(c.counts(), rep * fp.kmers()[2])
+                assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (rep * fp.total_kmers, rep * fp.total_hits, rep * fp.total_bases, rep * n)
+            for c in ctxs:                               # drop the merged view: the next round adds to the LOCAL counts again
+                c.set_max_hits(0, armed=False)
+            if rep == 1:
+                assert sum(c.sync().total_hits for c in ctxs) == fp.total_hits
+                assert all(0 < c.sync().total_hits < fp.total_hits for c in ctxs)     # every context really held a share
+        [c.close() for c in ctxs]
+    exe = os.path.join(ROOT, "build", "ntsmCount")
+    files = [str(tmp_path / ("%c.fq" % (97 + i))) for i in range(3)]
+    for i, f in enumerate(files):
+        s.write_fastq(f, 40_000 * i, 40_000)
+    base = subprocess.run([exe, "-s", path, "-g", "0"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert base.returncode == 0, base.stderr[-400:]
+    for g, t in (("0,0", "2"), ("0,0,0", "4")):
+        two = subprocess.run([exe, "-s", path, "-g", g, "-t", t] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             env=dict(os.environ, NTSM_BLOCK_BYTES="2000000"))
+        assert two.returncode == 0, two.stderr[-400:]
+        assert b"RCCL" not in two.stderr, two.stderr[-400:]          # one distinct device: no collective, no fallback message
+        assert two.stdout == base.stdout and _summary(two.stderr) == _summary(base.stderr), g
+    m1 = subprocess.run([exe, "-s", path, "-m", "0.01", "-g", "0"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    m2 = subprocess.run([exe, "-s", path, "-m", "0.01", "-g", "0,0", "-t", "2"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert m1.returncode == 0 and m2.returncode == 0, m2.stderr[-400:]
+    assert b"Reached desired" in m1.stderr and m2.stdout == m1.stdout and _summary(m2.stderr) == _summary(m1.stderr)
+
+
 @needs_two_gpus
 def test_bench_two_ranks_over_rccl(nt):
     """bench.py under torch.distributed.run with two ranks (one per GPU, RCCL): the contract line reports n_gpus = 2 and
