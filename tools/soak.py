@@ -7,6 +7,7 @@ equal.   tools/soak.py [seconds] [seed]"""
 import gzip, os, random, struct, subprocess, sys, tempfile, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE, ORA = os.path.join(ROOT, "build", "ntsmCount"), os.path.join(ROOT, "oracle", "ntsm_oracle")
+REFGPU = os.path.join(ROOT, "oracle", "_ref", "ref_gpu_ntsmCount")   # the reference's own class bound to the library (oracle/ref_gpu_binding.cpp), when it was built
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 KEEP = (b"Total ", b"Distinct ", b"Sites Covered", b"Warning: site coverage", b"Reached desired")
@@ -101,11 +102,29 @@ while time.time() < t_end:
     forms = [None, None, 1] + ([2] if 13 <= k <= 31 else []) + ([4] if 15 <= k <= 31 else []) + ([5, 5] if k == 19 else [])
     form = rng.choice(forms)
     kargs = ["--debug-kernel", str(form)] if form is not None else []
+    # round 6: several contexts on the one device (thread -> context round robin, one merge on the device: ntsm_allreduce)
+    g = rng.choice([None, None, "0,0", "0,0,0"])
+    if g:
+        kargs += ["-g", g]
     ref = subprocess.run([ORA] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     got = subprocess.run([EXE] + args + kargs + ["-t", str(t)] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     ok = (ref.returncode == got.returncode or (ref.returncode == 134 and got.returncode == -6)) and ref.stdout == got.stdout
     if ok and ref.returncode == 0:
         ok = summary(ref.stderr) == summary(got.stderr)
+    # round 6: the same inputs through the reference's OWN FingerPrint class with INTEGRATION.md's binding around it (site loader,
+    # kseq and printing are the reference's code, the counting is the library's); k = 32 is undefined behaviour in the reference
+    if ok and os.path.isfile(REFGPU) and k <= 31 and rng.random() < 0.5:
+        benv = dict(os.environ)
+        if rng.random() < 0.5:
+            benv["NTSM_REF_GPU_BATCH"] = str(rng.choice([8192, 100000]))
+        bnd = subprocess.run([REFGPU] + args + ["-t", str(rng.choice([1, 3]))] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=benv)
+        ok = (ref.returncode == bnd.returncode or (ref.returncode == 134 and bnd.returncode == -6)) and (ref.returncode != 0 or ref.stdout == bnd.stdout)
+        if ok and ref.returncode == 0:
+            ok = summary(ref.stderr) == summary(bnd.stderr)
+        if not ok:
+            got = bnd
+            kargs = ["(reference binding)"] + [x for x in benv.items() if x[0].startswith("NTSM_REF")]
+        n_binding = globals().get("n_binding", 0) + 1
     if not ok:
         fails += 1
         keep = tempfile.mkdtemp(prefix="ntsm_soak_fail_", dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
@@ -113,5 +132,5 @@ while time.time() < t_end:
         print(got.stderr.decode()[-600:])
         for p in [sp] + files:
             subprocess.run(["cp", p, keep])
-print("soak: %d iterations, %d mismatches" % (it, fails))
+print("soak: %d iterations (%d of them also through the reference binding), %d mismatches" % (it, globals().get("n_binding", 0), fails))
 sys.exit(1 if fails else 0)
