@@ -38,8 +38,8 @@ int ntsm_host_flatten(const char *path, uint8_t **bases, uint64_t *n_bytes, uint
 void ntsm_host_free(void *p);
 /* Test hook for the packed producer lanes (ntsm_amd/csrc/host/pack2.hpp; include/ntsm_hip.h ntsm_lane_acquire_packed):
  * append one read at position pos (a multiple of 8) of a packed batch -- 2-bit codes + 1 validity bit per position, the
- * five classes of vendor/KseqHashIterator.hpp:114-127 -- and return where the next read starts.  force_scalar != 0 runs
- * the portable implementation instead of the AVX2 one. */
+ * five classes of vendor/KseqHashIterator.hpp:114-127 -- and return where the next read starts.  force_scalar: 0 = the best
+ * implementation the CPU has (AVX-512 VBMI, AVX2, portable), 1 = the portable one, 2 = at most AVX2. */
 uint64_t ntsm_host_pack2_append(uint8_t *codes, uint8_t *valid, uint64_t pos, const uint8_t *seq, uint64_t len, int force_scalar);
 const char *ntsm_host_pack2_impl(void);
 /* Test hook for the gzip ingest (ntsm_amd/csrc/host/gz_stream.hpp): decode `path` with the decoder thread

@@ -83,9 +83,9 @@ void ntsm_host_free(void *p) { free(p); }
 
 uint64_t ntsm_host_pack2_append(uint8_t *codes, uint8_t *valid, uint64_t pos, const uint8_t *seq, uint64_t len, int force_scalar)
 {
-	ntsm::pack2_force_scalar(force_scalar != 0);
+	ntsm::pack2_force_impl(force_scalar);                     /* 0 = best available, 1 = portable, 2 = at most AVX2 */
 	const uint64_t r = ntsm::pack2_append(codes, valid, pos, (const char *) seq, len);
-	ntsm::pack2_force_scalar(false);
+	ntsm::pack2_force_impl(0);
 	return r;
 }
 const char *ntsm_host_pack2_impl(void) { return ntsm::pack2_impl(); }

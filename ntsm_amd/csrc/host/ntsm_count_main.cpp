@@ -25,6 +25,7 @@
 
 #include "fingerprint.hpp"
 #include "gz_stream.hpp"
+#include "pack2.hpp"
 
 #define PROGRAM "ntsmCount"
 
@@ -204,6 +205,7 @@ int main(int argc, char *argv[])
 	}
 	if (const char *bb = getenv("NTSM_BATCH_BYTES")) opt.batch_bytes = strtoull(bb, nullptr, 10);   /* staging slot size */
 	if (getenv("NTSM_NO_PACK")) opt.pack = false;                                                  /* lanes send raw bytes instead of 2-bit codes + validity */
+	if (const char *pi = getenv("NTSM_PACK_IMPL")) ntsm::pack2_force_impl(atoi(pi));               /* A/B of the packer: 0 best the CPU has (AVX-512 VBMI), 1 portable, 2 at most AVX2 */
 	if (const char *pb = getenv("NTSM_BLOCK_BYTES")) opt.block_bytes = strtoull(pb, nullptr, 10);   /* block-parallel ingest block size */
 	if (const char *gm = getenv("NTSM_GZ_PARALLEL_MIN")) opt.gz_parallel_min_bytes = strtoull(gm, nullptr, 10);   /* smallest gzip file that takes the decoder pool + piece-parallel parse (-t N) */
 	if (const char *gd = getenv("NTSM_GZ_DECODERS")) opt.gz_decoders = (unsigned) strtoul(gd, nullptr, 10);     /* decoder threads of that route */

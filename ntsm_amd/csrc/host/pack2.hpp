@@ -28,10 +28,11 @@ uint64_t pack2_append(uint8_t *codes, uint8_t *valid, uint64_t pos, const char *
 /* positions pack2_append() may write for a read of `len` bytes appended at `pos` */
 inline uint64_t pack2_extent(uint64_t pos, uint64_t len) { return pos + (len & ~31ull) + 32; }
 
-/* the implementation in use: "avx2" or "scalar" */
+/* the implementation in use: "avx512vbmi", "avx2" or "scalar" (chosen at run time from the CPU's feature bits) */
 const char *pack2_impl();
-/* test hook: force the portable implementation */
+/* test hooks: force the portable implementation / 0 = best available, 1 = portable, 2 = at most AVX2 */
 void pack2_force_scalar(bool on);
+void pack2_force_impl(int impl);
 
 } // namespace ntsm
 #endif

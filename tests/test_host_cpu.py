@@ -1288,8 +1288,8 @@ def test_pack2_packer_matches_the_byte_table(nt):
     table = np.array([L.ntsm_oracle_nt4(b) for b in range(256)], dtype=np.uint8)     # the oracle's copy of the reference table
     assert sorted(np.flatnonzero(table < 4).tolist()) == sorted([0, 1, 2, 3] + list(b"ACGTUacgtu"))
     rng = np.random.default_rng(3)
-    assert HO.ntsm_host_pack2_impl() in (b"avx2", b"scalar")
-    for force in (0, 1):
+    assert HO.ntsm_host_pack2_impl() in (b"avx512vbmi", b"avx2", b"scalar")
+    for force in (0, 1, 2):                               # best available (AVX-512 VBMI / AVX2), portable, at most AVX2
         for trial in range(120):
             reads = []
             for _ in range(int(rng.integers(1, 7))):

@@ -6,8 +6,9 @@
 #   exit    default (synchronous) | NTSM_FAST_EXIT=1 | NTSM_CLEAN_EXIT=1                      on plain and .gz
 #   gz      NTSM_GZ_DECODERS = 8 / 12 / 16 / 20 ; NTSM_GZ_CHUNK = 512 KiB / 2 MiB            on the .gz
 #   early   default | NTSM_NO_EARLY=1 | NTSM_EARLY=all                                        on plain and .gz
+#   pack    packer of the producer lanes: best the CPU has (AVX-512 VBMI) | NTSM_PACK_IMPL=2 (AVX2) | NTSM_NO_PACK=1 (raw bytes); with the phase times   on plain and .gz
 cd "$(dirname "$0")/.." || exit 1
-kind=${1:?usage: cli_ab.sh exit|gz|early [reads] [reps]}; reads=${2:-4e7}; reps=${3:-3}
+kind=${1:?usage: cli_ab.sh exit|gz|early|pack [reads] [reps]}; reads=${2:-4e7}; reps=${3:-3}
 out=gpurun_out/cli_ab_$kind; mkdir -p $out
 python3 - "$reads" <<'PY' > $out/prep.log 2>&1
 import sys
@@ -28,6 +29,10 @@ case $kind in
   exit)  sets=("NTSM_X=1" "NTSM_FAST_EXIT=1" "NTSM_CLEAN_EXIT=1"); files="/tmp/cli_ab.fq /tmp/cli_ab.fq.gz";;
   gz)    sets=("NTSM_GZ_DECODERS=8" "NTSM_GZ_DECODERS=12" "NTSM_GZ_DECODERS=16" "NTSM_GZ_DECODERS=20" "NTSM_GZ_CHUNK=524288" "NTSM_GZ_CHUNK=2097152"); files="/tmp/cli_ab.fq.gz";;
   early) sets=("NTSM_X=1" "NTSM_NO_EARLY=1" "NTSM_EARLY=all"); files="/tmp/cli_ab.fq /tmp/cli_ab.fq.gz";;
+  pack)  sets=("NTSM_PACK_IMPL=0" "NTSM_PACK_IMPL=2" "NTSM_NO_PACK=1"); files="/tmp/cli_ab.fq /tmp/cli_ab.fq.gz";;
   *) echo "unknown kind $kind"; exit 2;;
 esac
 for rep in $(seq $reps); do for f in $files; do for s in "${sets[@]}"; do one $f $s; done; done; done 2>&1 | tee $out/result.txt
+if [ $kind = pack ]; then   # where the time goes: the CLI's own phase lines, once per setting
+  for s in "${sets[@]}" "${sets[@]}"; do echo "== $s"; env $s NTSM_PHASE_TIMES=1 build/ntsmCount -s /tmp/cli_ab_sites.fa -t 16 /tmp/cli_ab.fq 2>&1 >/dev/null | grep -i "phase\|Time:"; done > $out/phases.txt 2>&1
+fi

@@ -131,6 +131,8 @@ int main(int argc, char **argv)
 		if (v) lane_counts.push_back(v);
 		p = q + 1;
 	}
+	const char *diag_env = getenv("FEED_DIAG");                  /* packed-lane legs only: packonly | nopack (see the lane loop) */
+	const int diag = !diag_env ? 0 : !strcmp(diag_env, "packonly") ? 1 : !strcmp(diag_env, "nopack") ? 2 : 0;
 	cpu_set_t aff;
 	const unsigned cpus = sched_getaffinity(0, sizeof aff, &aff) == 0 ? (unsigned) CPU_COUNT(&aff) : 1u;
 	const unsigned gen_threads = std::max(1u, std::min(32u, cpus));
@@ -317,20 +319,38 @@ int main(int argc, char **argv)
 			uint64_t link = 0;
 			if (packed) link = (n_reads * 152 + 31) / 32 * 12;          /* 3/8 byte per position */
 			else link = n_bytes;
-			leg(name, link, packed ? "the lane threads' packing (AVX2 pack2_append), not the link" : "the lane threads' memcpy into their pinned slots / the link",
+			leg(name, link, packed ? (std::string("the lane threads' packing (pack2_append, ") + ntsm::pack2_impl() + "), not the link").c_str() : "the lane threads' memcpy into their pinned slots / the link",
 				[&] {
 					std::atomic<int> err(0);
 					parallel(T, [&](unsigned t) {
 						ntsm_lane *ln = lanes[t];
 						const uint64_t r0 = n_reads * t / T, r1 = n_reads * (t + 1) / T;
-						if (packed) {
+						if (packed && diag == 1) {
+							/* diagnostic (FEED_DIAG=packonly): the packing alone, into a private buffer -- what the host side can produce */
+							std::vector<uint8_t> priv(cap_pos * 3 / 8 + 64);
+							for (uint64_t r = r0; r < r1;) {
+								uint64_t pos = 0;
+								while (r < r1 && ntsm::pack2_extent(pos, read_len) <= cap_pos) {
+									pos = ntsm::pack2_append(priv.data(), priv.data() + cap_pos / 4, pos, (const char *) stream + r * stride, read_len);
+									++r;
+								}
+							}
+						} else if (packed) {
+							uint64_t filled = 0, pos_full = 0, nb_full = 0; uint32_t nr_full = 0;
 							for (uint64_t r = r0; r < r1;) {
 								uint8_t *codes, *valid; uint64_t cap;
 								if (ntsm_lane_acquire_packed(ln, &codes, &valid, &cap)) { err = 1; return; }
 								uint64_t pos = 0; uint32_t nr = 0; uint64_t nb = 0;
-								while (r < r1 && ntsm::pack2_extent(pos, read_len) <= cap) {
-									pos = ntsm::pack2_append(codes, valid, pos, (const char *) stream + r * stride, read_len);
-									++r; ++nr; nb += read_len;
+								if (diag == 2 && filled >= 2 && r + nr_full <= r1) {
+									/* diagnostic (FEED_DIAG=nopack): both slots hold a full batch already -- hand the same bytes over again: what
+									 * the device side + the HIP calls take without the packing (counts are wrong by construction) */
+									pos = pos_full; nr = nr_full; nb = nb_full; r += nr_full;
+								} else {
+									while (r < r1 && ntsm::pack2_extent(pos, read_len) <= cap) {
+										pos = ntsm::pack2_append(codes, valid, pos, (const char *) stream + r * stride, read_len);
+										++r; ++nr; nb += read_len;
+									}
+									if (r < r1) { ++filled; pos_full = pos; nr_full = nr; nb_full = nb; }
 								}
 								if (ntsm_lane_submit_packed(ln, pos, nr, nb)) { err = 1; return; }
 							}
