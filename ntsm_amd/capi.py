@@ -460,7 +460,8 @@ class Lane:
         _chk(H.ntsm_lane_submit(self._h, bases.size, read_end.size), "ntsm_lane_submit")
 
     def submit_packed(self, reads, force_scalar=False):
-        """acquire_packed + pack every read (bytes objects) with the host packer + submit_packed"""
+        """acquire_packed + pack every read (bytes objects) with the host packer + submit_packed.  force_scalar: False / 0 = the
+        best form the CPU has (AVX-512 VBMI, AVX2), True / 1 = the portable one, 2 = at most AVX2"""
         pc, pv, cap = u8p(), u8p(), C.c_uint64()
         _chk(H.ntsm_lane_acquire_packed(self._h, C.byref(pc), C.byref(pv), C.byref(cap)), "ntsm_lane_acquire_packed")
         pos, n_bases = 0, 0

@@ -1207,7 +1207,7 @@ def test_producer_lanes_share_one_context(nt, tmp_path):
 def test_packed_lane_batches_vs_oracle(nt, tmp_path):
     """ntsm_lane_acquire_packed / ntsm_lane_submit_packed: 2-bit codes + a validity bit per position cross PCIe and are
     unpacked on the device.  Reads of every length 0..200 made of arbitrary bytes (all 256 values, raw codes 0..3,
-    lowercase, U, N runs), packed by the host packer (AVX2 and portable), mixed with byte batches on the same lane:
+    lowercase, U, N runs), packed by every form of the host packer (best the CPU has: AVX-512 VBMI or AVX2; portable; at most AVX2), mixed with byte batches on the same lane:
     counts, k-mer / hit / base / read totals equal the oracle's on the same reads."""
     rng = np.random.default_rng(11)
     k = 19
@@ -1234,7 +1234,7 @@ def test_packed_lane_batches_vs_oracle(nt, tmp_path):
     for r in reads:
         fp.process(r)
     assert fp.total_hits > 1000
-    for force_scalar in (False, True):
+    for force_scalar in (0, 1, 2):                          # ntsm_host_pack2_append: 0 best available, 1 portable, 2 at most AVX2
         ctx = nt.Context(sites.keys, k=k)
         lane = ctx.open_lane(1 << 20)
         flat_reads, chunk = [], 500
