@@ -407,10 +407,22 @@ int ntsm_lane_submit_packed(ntsm_lane *l, uint64_t n_positions, uint32_t n_reads
 	uint8_t *h_valid = s.h_bases + cap_pos / 4;
 	for (uint64_t p = n_positions; p < n_out; p += 8) h_valid[p >> 3] = 0;
 	{
-		void *const dst[2] = { s.d_packed, s.d_packed + cap_pos / 4 };
-		const void *const src[2] = { s.h_bases, h_valid };
-		const size_t bytes[2] = { (size_t) (n_out / 4), (size_t) (n_out / 8) };
-		LANECHK(slot_copy(c, s, dst, src, bytes, 2));
+		/* The two planes lie at the same offsets in the pinned slot and in its device image, so a (nearly) full batch crosses
+		 * as ONE copy -- the codes plane to its end, then the used part of the validity plane.  Every copy on the copy stream is
+		 * followed by ~50 us before the next one starts (profiles/r06_feed/lanes_packed_16.summary.txt), which is about what
+		 * a 3 MiB batch itself takes: the unused tail of the codes plane (at most 1 MiB here) is cheaper than a second copy. */
+		const uint64_t unused_codes = cap_pos / 4 - n_out / 4;
+		if (unused_codes <= (1ull << 20)) {
+			void *const dst[1] = { s.d_packed };
+			const void *const src[1] = { s.h_bases };
+			const size_t bytes[1] = { (size_t) (cap_pos / 4 + n_out / 8) };
+			LANECHK(slot_copy(c, s, dst, src, bytes, 1));
+		} else {
+			void *const dst[2] = { s.d_packed, s.d_packed + cap_pos / 4 };
+			const void *const src[2] = { s.h_bases, h_valid };
+			const size_t bytes[2] = { (size_t) (n_out / 4), (size_t) (n_out / 8) };
+			LANECHK(slot_copy(c, s, dst, src, bytes, 2));
+		}
 	}
 	const uint64_t n16 = n_out / 16;
 	LANECHK(launch_unpack((const uint32_t *) s.d_packed, (const uint16_t *) (s.d_packed + cap_pos / 4), s.d_bases, (unsigned long long) n16, s.stream));

@@ -319,7 +319,7 @@ int main(int argc, char **argv)
 			uint64_t link = 0;
 			if (packed) link = (n_reads * 152 + 31) / 32 * 12;          /* 3/8 byte per position */
 			else link = n_bytes;
-			leg(name, link, packed ? (std::string("the lane threads' packing (pack2_append, ") + ntsm::pack2_impl() + "), not the link").c_str() : "the lane threads' memcpy into their pinned slots / the link",
+			leg(name, link, packed ? (std::string("the lane threads' packing (pack2_append, ") + ntsm::pack2_impl() + ") up to ~8 lanes, then the device side of small batches (FEED_DIAG=packonly|nopack), not the link").c_str() : "the lane threads' memcpy into their pinned slots / the link",
 				[&] {
 					std::atomic<int> err(0);
 					parallel(T, [&](unsigned t) {
