@@ -1258,6 +1258,25 @@ def test_packed_lane_batches_vs_oracle(nt, tmp_path):
         t = ctx.sync()
         assert (t.total_kmers, t.total_hits, t.total_bases, t.reads_consumed) == (2 * fp.total_kmers, 2 * fp.total_hits, 2 * fp.total_bases, 2 * len(reads))
         assert np.array_equal(ctx.counts(), 2 * fp.kmers()[2])
+        if force_scalar == 0:
+            # an 8 MiB slot: a small batch crosses as two copies (codes, validity bits), a nearly full one as ONE copy of the codes
+            # plane to its end + the used part of the validity plane (capi.cpp: ntsm_lane_submit_packed) -- same counts either way
+            lane = ctx.open_lane(8 << 20, packed_only=True)
+            lane.submit_packed(reads[:chunk])                                   # ~60 k positions of 8 Mi: two copies
+            big, room = [], (8 << 20) - (1 << 20) // 2                          # fill to within 0.5 Mi positions of the slot's end: one copy
+            while room > 6000:
+                r = reads[len(big) % len(reads)]
+                big.append(r)
+                room -= (len(r) + 8) & ~7
+            lane.submit_packed(big)
+            lane.submit_packed(reads[chunk:2 * chunk])
+            lane.close()
+            fpb = OracleFP(path, k=k, dupes=True)
+            for r in reads[:2 * chunk] + big:
+                fpb.process(r)
+            t = ctx.sync()
+            assert (t.total_kmers, t.total_hits, t.total_bases) == (2 * fp.total_kmers + fpb.total_kmers, 2 * fp.total_hits + fpb.total_hits, 2 * fp.total_bases + fpb.total_bases)
+            assert np.array_equal(ctx.counts(), 2 * fp.kmers()[2] + fpb.kmers()[2])
         ctx.close()
 
 
