@@ -440,7 +440,14 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 				lut_reads(v, j0, e);
 				phase_a(e, S, j0, gg, fh, pm, m2);
 				if (TWO) phase_b(S);
+				/* Wave priority up for the phase that consumes the block loads, down again for the one that issues the next ones:
+				 * the four waves of a SIMD then leave phase C one after the other instead of sharing its issue slots, and each gets
+				 * its next loads out earlier.  1.54 M keys, interleaved A/B on two boxes: 911-917 against 903-908 Gbases/s (+1.0 %,
+				 * priority 1, 2 or 3 alike); raised in phase A instead -0.5 %, over the whole loop -1.2 %; the two-level form
+				 * (fabric-bound) does not move (NOTEBOOK R6.13). */
+				__builtin_amdgcn_s_setprio(2);
 				phase_c(S, t * C + b * 8 + j0);
+				__builtin_amdgcn_s_setprio(0);
 			}
 			block_end(gg, fh, m2);
 		}
