@@ -438,16 +438,21 @@ __global__ __launch_bounds__(kThreads, PER_READ ? 3 : NTSM_FAST_WAVES) void ntsm
 #pragma unroll
 			for (int j0 = 0; j0 < 8; j0 += HB) {
 				lut_reads(v, j0, e);
+				/* Wave priority: up for phase C -- the bit tests that consume the block loads -- and through the next step's table reads,
+				 * down again for phase A, which issues the next block loads: the four waves of a SIMD then leave phase C one after the
+				 * other instead of sharing its issue slots.  1.54 M keys, interleaved A/B on three boxes at 2e8 and 1e9 reads: 911-917
+				 * against 903-908 Gbases/s (+1.0 %; priority 1, 2 or 3 alike).  WHERE the priority drops matters: right after phase C
+				 * (the table reads at low priority) is 1 % SLOWER than no priority at all; raised in phase A instead -0.5 %, over the
+				 * whole loop -1.2 %; the two-level form (fabric-bound) does not move (NOTEBOOK R6.13).  -DNTSM_NO_PRIO: A/B builds. */
+#ifndef NTSM_NO_PRIO
+				__builtin_amdgcn_s_setprio(0);
+#endif
 				phase_a(e, S, j0, gg, fh, pm, m2);
 				if (TWO) phase_b(S);
-				/* Wave priority up for the phase that consumes the block loads, down again for the one that issues the next ones:
-				 * the four waves of a SIMD then leave phase C one after the other instead of sharing its issue slots, and each gets
-				 * its next loads out earlier.  1.54 M keys, interleaved A/B on two boxes: 911-917 against 903-908 Gbases/s (+1.0 %,
-				 * priority 1, 2 or 3 alike); raised in phase A instead -0.5 %, over the whole loop -1.2 %; the two-level form
-				 * (fabric-bound) does not move (NOTEBOOK R6.13). */
+#ifndef NTSM_NO_PRIO
 				__builtin_amdgcn_s_setprio(2);
+#endif
 				phase_c(S, t * C + b * 8 + j0);
-				__builtin_amdgcn_s_setprio(0);
 			}
 			block_end(gg, fh, m2);
 		}
