@@ -200,6 +200,13 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 	uint4 s_blk = make_uint4(0, 0, 0, 0);
 	bool s_v = false;
 	auto process = [&](bool take) {
+		/* Wave priority (as in kernels_mz.hip, NOTEBOOK R6.13): low for the stage that tests the fetched blocks and requests the next
+		 * ones, raised again behind the main loop's next table reads.  2.5 M keys, interleaved on two boxes: 828.6-831.5 against
+		 * 821.9-824.7 Gbases/s (+0.8 %); the other way round (raised here, dropped in the loop) +0.2 %, raised around this stage only
+		 * -0.7 %.  -DNTSM_NO_PRIO: A/B builds. */
+#ifndef NTSM_NO_PRIO
+		__builtin_amdgcn_s_setprio(0);
+#endif
 		/* stage 2 */
 		uint32_t cls = 0;
 		if (s_v) {
@@ -323,6 +330,9 @@ __global__ __launch_bounds__(kThreads, NTSM_RUN_WAVES) void ntsm_count_run_kerne
 			uint2 e[8];
 #pragma unroll
 			for (int j = 0; j < 8; ++j) e[j] = lut64[(w[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
+#ifndef NTSM_NO_PRIO
+			__builtin_amdgcn_s_setprio(2);
+#endif
 			uint32_t gg[8], t3[8];
 			const uint32_t pcb = (uint32_t) __builtin_amdgcn_readfirstlane((b & 1) << 3);   /* scalar: position mod 16 = pcb | j */
 #pragma unroll
